@@ -1,0 +1,174 @@
+/*
+ * splat2d.h -- C ABI of the MI355X-native 2D Gaussian splatting trainer.
+ *
+ * The reference (Ushio/2dGaussianSplatting, /root/reference/main.cpp) has no
+ * plugin / FFI interface: the forward rasteriser, the analytic backward pass and
+ * the Adam step are inline loops inside main()'s frame loop (main.cpp:334-851)
+ * that communicate through main()'s locals.  This boundary is therefore drawn
+ * around the locals those three passes own:
+ *
+ *   std::vector<Splat> splats          main.cpp:272      <-> s2d_set_splats / s2d_get_splats
+ *   std::vector<SplatAdam> splatAdams  main.cpp:276      <-> s2d_set_adam / s2d_get_adam
+ *   float beta1t, beta2t               main.cpp:274-275  <-> s2d_set_adam / s2d_get_adam
+ *   int iterations                     main.cpp:278      <-> s2d_set_adam / s2d_get_adam
+ *   Image2DRGBA32 imageRef             main.cpp:254-259  <-> s2d_set_target
+ *   Image2DRGBA32 image0               main.cpp:310      <-> s2d_get_image
+ *   std::vector<Splat> dSplats         main.cpp:550      <-> s2d_get_grads
+ *   bool optimizeOpacity               main.cpp:317      <-> S2D_STEP_OPTIMIZE_OPACITY
+ *   float trainingRate                 main.cpp:715      <-> s2d_config.training_rate
+ *   abort() on non-finite params       main.cpp:752-785  <-> status S2D_E_NONFINITE
+ *
+ * Conventions: plain C, opaque handle, int status returns (0 = OK), no exceptions
+ * or aborts across the boundary.  All `const T*` / `T*` arguments are HOST pointers
+ * owned by the caller unless the name says `_device`.  A context is driven by one
+ * host thread; it owns its device memory; work is queued on its HIP stream and
+ * host-visible results are complete when the call that returns them returns.
+ *
+ * There is NO CPU fallback: every entry point that computes runs hand-written
+ * HIP kernels for gfx950 and fails with S2D_E_HIP when no device is usable.
+ */
+#ifndef SPLAT2D_H
+#define SPLAT2D_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define S2D_ABI_VERSION 1
+
+/* == struct Splat, main.cpp:85-93 (vec2 pos; float sx, sy, rot; vec3 color; float opacity): 36 bytes.
+ * Also the gradient record (dSplats, main.cpp:550). */
+typedef struct s2d_splat {
+    float pos[2];
+    float sx, sy, rot;
+    float color[3];
+    float opacity;
+} s2d_splat;
+
+/* == struct Adam, main.cpp:139-157 */
+typedef struct s2d_adam { float m, v; } s2d_adam;
+
+/* == struct SplatAdam, main.cpp:158-166: 72 bytes */
+typedef struct s2d_splat_adam {
+    s2d_adam pos[2];
+    s2d_adam sx, sy, rot;
+    s2d_adam color[3];
+    s2d_adam opacity;
+} s2d_splat_adam;
+
+typedef enum s2d_status {
+    S2D_OK = 0,
+    S2D_E_INVALID = 1,    /* bad argument / bad config */
+    S2D_E_HIP = 2,        /* HIP runtime error or no usable gfx950 device (see s2d_last_error) */
+    S2D_E_NONFINITE = 3,  /* a parameter the reference checks (main.cpp:752-785) became non-finite */
+    S2D_E_NOMEM = 4,
+    S2D_E_STATE = 5       /* call order violated (e.g. backward before forward, no target set) */
+} s2d_status;
+
+/* s2d_step / s2d_adam_step flags */
+#define S2D_STEP_OPTIMIZE_OPACITY 0x1u /* the "Optimize opacity" checkbox, main.cpp:317, :735-738, :825 */
+
+/* s2d_config.flags */
+#define S2D_CFG_COUNT_PAIRS 0x1u /* count visited / active pixel-splat pairs in the raster kernels (diagnostic) */
+
+typedef struct s2d_config {
+    uint32_t struct_size;   /* = sizeof(s2d_config) */
+    int32_t width, height;  /* imageRef.width(), .height() (main.cpp:254) */
+    int32_t n_splats;       /* NSplat (main.cpp:271) */
+    int32_t device;         /* HIP device ordinal */
+    /* Row slab [row_begin, row_end) of the image this context rasterises.
+     * 0,0 = the whole image.  row_begin must be a multiple of 16 (the tile height). */
+    int32_t row_begin, row_end;
+    float training_rate;    /* 0 -> 0.05f (main.cpp:715) */
+    uint32_t flags;         /* S2D_CFG_* */
+    int32_t rebin_interval; /* iterations between re-binning of the tile lists; 0 -> library default */
+    void* stream;           /* hipStream_t to queue work on; NULL -> the context creates its own */
+} s2d_config;
+
+typedef struct s2d_stats {
+    uint64_t pairs_binned;     /* (tile, splat) pairs in the current tile lists */
+    uint64_t pairs_capacity;
+    uint64_t rebins;           /* times the tile lists were rebuilt */
+    uint64_t fwd_visited, fwd_active; /* S2D_CFG_COUNT_PAIRS: pairs inside the reference's x/y ranges, and those with T >= 1/256 */
+    uint64_t bwd_visited, bwd_active;
+    uint64_t fwd_staged, bwd_staged;  /* list entries the raster kernels actually staged (after tile retirement) */
+    int32_t iterations;        /* == `iterations`, main.cpp:278 */
+    int32_t first_nonfinite_iteration; /* -1 if none */
+} s2d_stats;
+
+typedef struct s2d_ctx s2d_ctx;
+
+int s2d_abi_version(void);
+
+/* Allocates device state for (width, height, n_splats).  Splats are zero until s2d_init_splats / s2d_set_splats. */
+int s2d_create(const s2d_config* cfg, s2d_ctx** out);
+void s2d_destroy(s2d_ctx* ctx);
+
+/* imageRef (main.cpp:254-259): width*height RGBA32F, row-major, .rgb in [0,1]; copied. */
+int s2d_set_target(s2d_ctx* ctx, const float* rgba32f);
+/* Fills imageRef on the device with ref(x,y) = (x/W, 1 - x/W, y/H, 1): the reference's commented generator
+ * (main.cpp:261-267) plus a blue ramp, evaluated in fp32. */
+int s2d_set_target_synthetic(s2d_ctx* ctx);
+
+/* init(), main.cpp:280-305: pcg3d-seeded splats, Adam state zeroed, beta powers = 1, iterations = 0. */
+int s2d_init_splats(s2d_ctx* ctx);
+int s2d_set_splats(s2d_ctx* ctx, const s2d_splat* splats);
+int s2d_get_splats(s2d_ctx* ctx, s2d_splat* splats);
+/* Checkpointable optimiser state (main.cpp:274-278). */
+int s2d_set_adam(s2d_ctx* ctx, const s2d_splat_adam* adams, float beta1t, float beta2t, int32_t iterations);
+int s2d_get_adam(s2d_ctx* ctx, s2d_splat_adam* adams, float* beta1t, float* beta2t, int32_t* iterations);
+
+/* Forward rasteriser, main.cpp:414-546 (rows of this context's slab). */
+int s2d_forward(s2d_ctx* ctx);
+/* image0 as uploaded at main.cpp:794: width*height RGBA32F, .w = 1.  Rows outside the slab are returned as 0. */
+int s2d_get_image(s2d_ctx* ctx, float* rgba32f);
+
+/* Backward pass, main.cpp:548-712: accumulates this slab's contribution into the gradient buffer
+ * (which s2d_adam_step / s2d_step re-zero after use, like main.cpp:550).  Needs s2d_forward first. */
+int s2d_backward(s2d_ctx* ctx);
+int s2d_get_grads(s2d_ctx* ctx, s2d_splat* dsplats);
+
+/* Adam + constraints + finite guard, main.cpp:714-785, on the current gradient buffer; then iterations++ (809). */
+int s2d_adam_step(s2d_ctx* ctx, uint32_t flags);
+
+/* `iters` whole iterations (main.cpp:414-809): forward, backward, Adam, MSE.  mse_out (may be NULL) receives
+ * iters doubles: the value the reference prints for each iteration (main.cpp:796-807).  For a slab context the
+ * values are this slab's sum of squared errors divided by (H*W*3), i.e. partial MSEs that add up over slabs.
+ * Returns S2D_E_NONFINITE where the reference would abort(). */
+int s2d_step(s2d_ctx* ctx, int32_t iters, uint32_t flags, double* mse_out);
+
+/* MSE (main.cpp:796-805) of the framebuffer produced by the last s2d_forward / s2d_backward pair. */
+int s2d_get_mse(s2d_ctx* ctx, double* mse);
+
+/* ---- multi-GPU plumbing (one process per GPU; the host all-reduces between backward and Adam) ---- */
+/* Use caller-owned DEVICE memory (n_splats * 9 floats, layout s2d_splat[n]) as the gradient buffer, so the host
+ * can all-reduce it in place (RCCL).  NULL -> back to the context's own buffer.  The buffer must be zero when
+ * bound and is re-zeroed by s2d_adam_step. */
+int s2d_bind_grads_device(s2d_ctx* ctx, void* grads_device);
+/* Device address of the gradient buffer currently in use. */
+void* s2d_grads_device_ptr(s2d_ctx* ctx);
+/* Per-iteration sums of squared errors of this slab kept on the device (ring of `capacity` doubles indexed by
+ * iteration % capacity); lets a multi-GPU host reduce them once after many steps instead of every iteration. */
+int s2d_get_sqerr_trace(s2d_ctx* ctx, int32_t first_iteration, int32_t count, double* out);
+int s2d_synchronize(s2d_ctx* ctx);
+
+int s2d_get_stats(s2d_ctx* ctx, s2d_stats* out);
+const char* s2d_last_error(const s2d_ctx* ctx);
+
+/* ---- test hooks (used by tests/ through this ABI; not part of the training path) ---- */
+/* Device trig used by the projection kernel, evaluated on the GPU for n host floats. */
+int s2d_test_sincos(int32_t device, const float* x, int32_t n, float* sin_out, float* cos_out);
+/* Stable LSD radix sort of (key, value) pairs by the low `key_bits` bits of key, on the GPU. */
+int s2d_test_sort_pairs(int32_t device, uint32_t* keys, uint32_t* values, int64_t n, int32_t key_bits);
+/* Exclusive prefix sum on the GPU; returns the total in *total. */
+int s2d_test_exclusive_scan(int32_t device, uint32_t* data, int64_t n, uint64_t* total);
+/* The tile lists the raster kernels walk, for inspection: offsets has tiles+1 entries. */
+int s2d_debug_get_tile_lists(s2d_ctx* ctx, int32_t* tiles_x, int32_t* tiles_y, uint32_t* offsets,
+                             int64_t offsets_capacity, uint32_t* list, int64_t list_capacity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPLAT2D_H */
