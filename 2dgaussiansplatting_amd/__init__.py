@@ -1,0 +1,264 @@
+"""MI355X-native 2D Gaussian splatting trainer: Python host-side binding of the C ABI.
+
+The product is `lib/libsplat2d_hip.so` (hand-written HIP for gfx950 behind include/splat2d.h).
+This module only binds it with ctypes for tests and bench.py; `Trainer` holds the same state the
+reference keeps in main()'s locals (/root/reference/main.cpp:272-278, :310-317) and exposes the
+three passes under the reference's names.  There is no CPU path here: importing works anywhere,
+but every compute call needs the built library and a gfx950 device and raises otherwise.
+
+The package name starts with a digit, so import it with
+    importlib.import_module("2dgaussiansplatting_amd")
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+__all__ = ["Trainer", "S2DError", "load_library", "SPLAT_DTYPE", "ADAM_DTYPE", "STATUS_NAMES"]
+
+# == struct Splat (main.cpp:85-93), 36 bytes; == struct SplatAdam (main.cpp:158-166), 72 bytes
+SPLAT_DTYPE = np.dtype([("pos", "<f4", 2), ("sx", "<f4"), ("sy", "<f4"), ("rot", "<f4"),
+                        ("color", "<f4", 3), ("opacity", "<f4")])
+ADAM_DTYPE = np.dtype([("mv", "<f4", (9, 2))])
+
+S2D_STEP_OPTIMIZE_OPACITY = 0x1
+S2D_CFG_COUNT_PAIRS = 0x1
+STATUS_NAMES = {0: "S2D_OK", 1: "S2D_E_INVALID", 2: "S2D_E_HIP", 3: "S2D_E_NONFINITE", 4: "S2D_E_NOMEM",
+                5: "S2D_E_STATE"}
+
+
+class S2DError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (STATUS_NAMES.get(code, code), msg))
+        self.code = code
+
+
+class _Config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
+                ("n_splats", C.c_int32), ("device", C.c_int32), ("row_begin", C.c_int32),
+                ("row_end", C.c_int32), ("training_rate", C.c_float), ("flags", C.c_uint32),
+                ("rebin_interval", C.c_int32), ("stream", C.c_void_p)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("pairs_binned", C.c_uint64), ("pairs_capacity", C.c_uint64), ("rebins", C.c_uint64),
+                ("fwd_visited", C.c_uint64), ("fwd_active", C.c_uint64), ("bwd_visited", C.c_uint64),
+                ("bwd_active", C.c_uint64), ("fwd_staged", C.c_uint64), ("bwd_staged", C.c_uint64),
+                ("iterations", C.c_int32), ("first_nonfinite_iteration", C.c_int32)]
+
+
+# every symbol include/splat2d.h declares
+ABI_SYMBOLS = [
+    "s2d_abi_version", "s2d_create", "s2d_destroy", "s2d_set_target", "s2d_set_target_synthetic",
+    "s2d_init_splats", "s2d_set_splats", "s2d_get_splats", "s2d_set_adam", "s2d_get_adam", "s2d_forward",
+    "s2d_get_image", "s2d_backward", "s2d_get_grads", "s2d_adam_step", "s2d_step", "s2d_get_mse",
+    "s2d_bind_grads_device", "s2d_grads_device_ptr", "s2d_get_sqerr_trace", "s2d_synchronize", "s2d_get_stats",
+    "s2d_last_error", "s2d_test_sincos", "s2d_test_sort_pairs", "s2d_test_exclusive_scan",
+    "s2d_debug_get_tile_lists",
+]
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the HIP library.  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or _build.LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the trainer has no CPU fallback)" % path)
+    L = C.CDLL(path)
+    vp, i32, u32, i64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64
+    L.s2d_abi_version.restype = C.c_int
+    L.s2d_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
+    L.s2d_destroy.argtypes = [vp]
+    L.s2d_destroy.restype = None
+    L.s2d_set_target.argtypes = [vp, vp]
+    L.s2d_set_target_synthetic.argtypes = [vp]
+    L.s2d_init_splats.argtypes = [vp]
+    L.s2d_set_splats.argtypes = [vp, vp]
+    L.s2d_get_splats.argtypes = [vp, vp]
+    L.s2d_set_adam.argtypes = [vp, vp, C.c_float, C.c_float, i32]
+    L.s2d_get_adam.argtypes = [vp, vp, vp, vp, vp]
+    L.s2d_forward.argtypes = [vp]
+    L.s2d_get_image.argtypes = [vp, vp]
+    L.s2d_backward.argtypes = [vp]
+    L.s2d_get_grads.argtypes = [vp, vp]
+    L.s2d_adam_step.argtypes = [vp, u32]
+    L.s2d_step.argtypes = [vp, i32, u32, vp]
+    L.s2d_get_mse.argtypes = [vp, vp]
+    L.s2d_bind_grads_device.argtypes = [vp, vp]
+    L.s2d_grads_device_ptr.argtypes = [vp]
+    L.s2d_grads_device_ptr.restype = vp
+    L.s2d_get_sqerr_trace.argtypes = [vp, i32, i32, vp]
+    L.s2d_synchronize.argtypes = [vp]
+    L.s2d_get_stats.argtypes = [vp, C.POINTER(_Stats)]
+    L.s2d_last_error.argtypes = [vp]
+    L.s2d_last_error.restype = C.c_char_p
+    L.s2d_test_sincos.argtypes = [i32, vp, i32, vp, vp]
+    L.s2d_test_sort_pairs.argtypes = [i32, vp, vp, i64, i32]
+    L.s2d_test_exclusive_scan.argtypes = [i32, vp, i64, vp]
+    L.s2d_debug_get_tile_lists.argtypes = [vp, vp, vp, vp, i64, vp, i64]
+    if path == _build.LIB_PATH:
+        _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Trainer:
+    """The reference's training state and its three passes, on one MI355X (or one row slab of the image).
+
+    Mirrors main()'s locals: splats / splatAdams / beta1t / beta2t / iterations (main.cpp:272-278),
+    imageRef (:254), image0 (:310), optimizeOpacity (:317).
+    """
+
+    def __init__(self, width, height, n_splats, device=0, row_begin=0, row_end=0, training_rate=0.0,
+                 rebin_interval=0, count_pairs=False, stream=None):
+        self.L = load_library()
+        self.W, self.H, self.n = int(width), int(height), int(n_splats)
+        cfg = _Config()
+        cfg.struct_size = C.sizeof(_Config)
+        cfg.width, cfg.height, cfg.n_splats, cfg.device = self.W, self.H, self.n, int(device)
+        cfg.row_begin, cfg.row_end = int(row_begin), int(row_end)
+        cfg.training_rate = float(training_rate)
+        cfg.flags = S2D_CFG_COUNT_PAIRS if count_pairs else 0
+        cfg.rebin_interval = int(rebin_interval)
+        cfg.stream = stream
+        h = C.c_void_p()
+        rc = self.L.s2d_create(C.byref(cfg), C.byref(h))
+        self._h = h
+        if rc != 0:
+            msg = self.L.s2d_last_error(h).decode() if h else "s2d_create rejected the configuration"
+            if h:
+                self.L.s2d_destroy(h)
+            self._h = None
+            raise S2DError(rc, msg)
+        self.optimize_opacity = False  # main.cpp:317
+
+    # -- lifetime
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.s2d_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise S2DError(rc, self.L.s2d_last_error(self._h).decode())
+
+    def _flags(self):
+        return S2D_STEP_OPTIMIZE_OPACITY if self.optimize_opacity else 0
+
+    # -- state
+    def set_target(self, rgba32f):
+        a = np.ascontiguousarray(rgba32f, dtype=np.float32)
+        assert a.shape == (self.H, self.W, 4), a.shape
+        self._ck(self.L.s2d_set_target(self._h, _p(a)))
+
+    def set_target_synthetic(self):
+        self._ck(self.L.s2d_set_target_synthetic(self._h))
+
+    def init(self):
+        """init(), main.cpp:280-305 (also what the Restart button calls, :828-831)."""
+        self._ck(self.L.s2d_init_splats(self._h))
+
+    def set_splats(self, splats):
+        a = np.ascontiguousarray(splats, dtype=SPLAT_DTYPE)
+        assert a.shape == (self.n,)
+        self._ck(self.L.s2d_set_splats(self._h, _p(a)))
+
+    def get_splats(self):
+        a = np.zeros(self.n, dtype=SPLAT_DTYPE)
+        self._ck(self.L.s2d_get_splats(self._h, _p(a)))
+        return a
+
+    def set_adam(self, adams, beta1t, beta2t, iterations):
+        a = np.ascontiguousarray(adams, dtype=ADAM_DTYPE)
+        assert a.shape == (self.n,)
+        self._ck(self.L.s2d_set_adam(self._h, _p(a), float(beta1t), float(beta2t), int(iterations)))
+
+    def get_adam(self):
+        a = np.zeros(self.n, dtype=ADAM_DTYPE)
+        b1, b2, it = C.c_float(), C.c_float(), C.c_int32()
+        self._ck(self.L.s2d_get_adam(self._h, _p(a), C.byref(b1), C.byref(b2), C.byref(it)))
+        return a, np.float32(b1.value), np.float32(b2.value), it.value
+
+    # -- the three passes
+    def forward(self):
+        self._ck(self.L.s2d_forward(self._h))
+
+    def get_image(self):
+        a = np.zeros((self.H, self.W, 4), dtype=np.float32)
+        self._ck(self.L.s2d_get_image(self._h, _p(a)))
+        return a
+
+    def backward(self):
+        self._ck(self.L.s2d_backward(self._h))
+
+    def get_grads(self):
+        a = np.zeros(self.n, dtype=SPLAT_DTYPE)
+        self._ck(self.L.s2d_get_grads(self._h, _p(a)))
+        return a
+
+    def adam_step(self):
+        self._ck(self.L.s2d_adam_step(self._h, self._flags()))
+
+    def step(self, iters=1, want_mse=True):
+        """iters whole iterations; returns the MSE values the reference would print (main.cpp:807)."""
+        out = np.zeros(iters, dtype=np.float64) if want_mse else None
+        self._ck(self.L.s2d_step(self._h, int(iters), self._flags(), _p(out) if want_mse else None))
+        return out
+
+    def mse(self):
+        v = C.c_double()
+        self._ck(self.L.s2d_get_mse(self._h, C.byref(v)))
+        return v.value
+
+    def sqerr_trace(self, first_iteration, count):
+        out = np.zeros(count, dtype=np.float64)
+        self._ck(self.L.s2d_get_sqerr_trace(self._h, int(first_iteration), int(count), _p(out)))
+        return out
+
+    def synchronize(self):
+        self._ck(self.L.s2d_synchronize(self._h))
+
+    # -- multi-GPU plumbing
+    def bind_grads(self, device_ptr):
+        self._ck(self.L.s2d_bind_grads_device(self._h, C.c_void_p(device_ptr) if device_ptr else None))
+
+    def grads_device_ptr(self):
+        return self.L.s2d_grads_device_ptr(self._h)
+
+    # -- diagnostics
+    def stats(self):
+        s = _Stats()
+        self._ck(self.L.s2d_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in _Stats._fields_}
+
+    def tile_lists(self):
+        st = self.stats()
+        tx, ty = C.c_int32(), C.c_int32()
+        self._ck(self.L.s2d_debug_get_tile_lists(self._h, C.byref(tx), C.byref(ty), None, 0, None, 0))
+        off = np.zeros(tx.value * ty.value + 1, dtype=np.uint32)
+        lst = np.zeros(max(int(st["pairs_binned"]), 1), dtype=np.uint32)
+        self._ck(self.L.s2d_debug_get_tile_lists(self._h, C.byref(tx), C.byref(ty), _p(off), len(off),
+                                                 _p(lst), len(lst)))
+        return tx.value, ty.value, off, lst[:int(st["pairs_binned"])]

@@ -1,0 +1,72 @@
+"""Build helpers: compile the HIP library (gfx950) and the C++ host program in-tree.
+
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the build container; the
+resulting .so travels to the GPU box with the repo snapshot (it is git-ignored, not
+gpurun-ignored).
+"""
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_DIR = os.path.join(PKG_DIR, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libsplat2d_hip.so")
+HOST_DIR = os.path.join(PKG_DIR, "host")
+TRAIN_BIN = os.path.join(LIB_DIR, "splat2d_train")
+
+HIP_SOURCES = ["s2d_api.hip", "s2d_scan_sort.hip", "s2d_binning.hip", "s2d_raster.hip", "s2d_optim.hip"]
+HIP_HEADERS = ["s2d_device.h", "s2d_math.h"]
+
+# -ffp-contract=off: the kernels keep the reference's evaluation order (no FMA contraction) wherever a
+# discrete decision or the framebuffer depends on it; fp32 divide/sqrt stay correctly rounded (hipcc default).
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
+               "-Wall", "-Wno-unused-function"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the MI355X library cannot be built (there is no CPU fallback)")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip_library(force=False, verbose=False):
+    srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "splat2d.h")]
+    if force or _stale(LIB_PATH, deps):
+        os.makedirs(LIB_DIR, exist_ok=True)
+        cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def build_host_program(force=False, verbose=False):
+    """The headless C++ host loop (mirrors main.cpp's frame loop) on top of the C ABI."""
+    src = os.path.join(HOST_DIR, "splat2d_train.cpp")
+    if not os.path.exists(src):
+        return None
+    deps = [src, os.path.join(ROOT, "include", "splat2d.h"), LIB_PATH]
+    if force or _stale(TRAIN_BIN, deps):
+        cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", TRAIN_BIN, src,
+               "-L", LIB_DIR, "-lsplat2d_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return TRAIN_BIN
+
+
+def build_all(force=False, verbose=False):
+    lib = build_hip_library(force=force, verbose=verbose)
+    build_host_program(force=force, verbose=verbose)
+    return lib

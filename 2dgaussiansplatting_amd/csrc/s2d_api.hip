@@ -1,0 +1,645 @@
+// s2d_api.hip -- the C ABI of include/splat2d.h: context, device memory, iteration sequencing.
+//
+// One iteration (main.cpp:414-809) is queued on the context's stream as
+//   project -> [count scan -> emit -> radix sort -> tile offsets]   (tile lists, when due)
+//   raster_forward -> raster_backward (+ per-tile squared error) -> sqerr_finalize -> adam
+// with no host synchronisation except the 4-byte read of the pair count when the lists are rebuilt.
+#include "../../include/splat2d.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "s2d_device.h"
+
+using namespace s2d;
+
+struct s2d_ctx {
+    s2d_config cfg{};
+    Geometry g{};
+    int n = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    float lr = 0.05f;
+
+    // parameters / optimiser state / gradients (AoS, the reference's layouts)
+    float* d_splats = nullptr;   // n * 9
+    float* d_adams = nullptr;    // n * 18
+    float* d_grads_own = nullptr;
+    float* d_grads = nullptr;    // buffer in use (own or bound)
+    // projection + binning
+    ProjRec* d_proj = nullptr;
+    TileRect* d_rects = nullptr;
+    uint32_t* d_counts = nullptr;
+    uint32_t* d_offsets = nullptr;
+    uint32_t* d_scan_temp = nullptr;
+    uint32_t* d_total = nullptr;
+    uint32_t* d_keys[2] = {nullptr, nullptr};
+    uint32_t* d_vals[2] = {nullptr, nullptr};
+    uint32_t* d_sort_temp = nullptr;
+    uint64_t pair_capacity = 0;
+    uint32_t* d_tile_off = nullptr;
+    uint32_t* d_list = nullptr; // == one of d_vals after the sort
+    uint64_t pairs = 0;
+    uint64_t rebins = 0;
+    bool lists_valid = false;
+    int rebin_interval = 1;
+    int since_rebin = 0;
+    float margin = 0.0f;
+    // images
+    float4* d_image0 = nullptr;
+    float4* d_ref = nullptr;
+    double* d_tile_sqerr = nullptr;
+    double* d_sqerr_trace = nullptr;
+    int trace_cap = 1 << 16;
+    DeviceStatus* d_status = nullptr;
+    PairCounters* d_counters = nullptr;
+    // pinned host mirrors
+    uint32_t* h_total = nullptr;
+    DeviceStatus* h_status = nullptr;
+
+    // host-side state of the reference's main()
+    float beta1t = 1.0f, beta2t = 1.0f; // main.cpp:274-275
+    int iterations = 0;                 // main.cpp:278
+    bool have_target = false;
+    bool have_forward = false;
+    bool have_backward = false;
+    int last_sqerr_slot = -1;
+    char err[512] = {0};
+};
+
+namespace {
+
+int fail(s2d_ctx* c, int code, const char* fmt, ...)
+{
+    if (c) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(c->err, sizeof(c->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+#define S2D_HIP(c, expr)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (expr);                                                                       \
+        if (e_ != hipSuccess)                                                                         \
+            return fail((c), S2D_E_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+hipError_t dev_alloc(T** p, size_t count)
+{
+    return hipMalloc((void**)p, std::max<size_t>(count, 1) * sizeof(T));
+}
+
+int use_device(s2d_ctx* c)
+{
+    S2D_HIP(c, hipSetDevice(c->device));
+    return S2D_OK;
+}
+
+int key_bits_for(int num_tiles)
+{
+    int bits = 0;
+    while ((1 << bits) < num_tiles) bits++;
+    return bits;
+}
+
+int ensure_pair_capacity(s2d_ctx* c, uint64_t need)
+{
+    if (need <= c->pair_capacity) return S2D_OK;
+    if (need >= 0xFFFF0000ull) return fail(c, S2D_E_NOMEM, "tile lists need %llu pairs (> 2^32)", (unsigned long long)need);
+    uint64_t cap = std::max<uint64_t>(need + need / 4 + 4096, 1 << 16);
+    if (cap > 0xFFFF0000ull) cap = 0xFFFF0000ull;
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    for (int k = 0; k < 2; k++) {
+        if (c->d_keys[k]) S2D_HIP(c, hipFree(c->d_keys[k]));
+        if (c->d_vals[k]) S2D_HIP(c, hipFree(c->d_vals[k]));
+        c->d_keys[k] = c->d_vals[k] = nullptr;
+    }
+    if (c->d_sort_temp) S2D_HIP(c, hipFree(c->d_sort_temp));
+    c->d_sort_temp = nullptr;
+    c->pair_capacity = 0;
+    for (int k = 0; k < 2; k++) {
+        S2D_HIP(c, dev_alloc(&c->d_keys[k], cap));
+        S2D_HIP(c, dev_alloc(&c->d_vals[k], cap));
+    }
+    S2D_HIP(c, dev_alloc(&c->d_sort_temp, sort_temp_words((int64_t)cap)));
+    c->pair_capacity = cap;
+    return S2D_OK;
+}
+
+// (Re)build the per-tile lists from the current parameters.  The projection has already been queued with mode 0.
+int rebuild_lists(s2d_ctx* c)
+{
+    const int n = c->n;
+    S2D_HIP(c, exclusive_scan_u32(c->d_counts, c->d_offsets, n, c->d_scan_temp, c->d_total, c->stream));
+    S2D_HIP(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    const uint64_t total = *c->h_total;
+    int rc = ensure_pair_capacity(c, total);
+    if (rc != S2D_OK) return rc;
+    S2D_HIP(c, launch_emit_pairs(c->d_rects, c->d_offsets, n, c->g, c->d_keys[0], c->d_vals[0],
+                                 (uint32_t)c->pair_capacity, c->stream));
+    uint32_t *k_out = nullptr, *v_out = nullptr;
+    S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)total,
+                              key_bits_for(c->g.num_tiles), c->d_sort_temp, &k_out, &v_out, c->stream));
+    S2D_HIP(c, launch_tile_offsets(k_out, (uint32_t)total, c->g.num_tiles, c->d_tile_off, c->stream));
+    c->d_list = v_out;
+    c->pairs = total;
+    c->rebins++;
+    c->lists_valid = true;
+    c->since_rebin = 0;
+    return S2D_OK;
+}
+
+// Project the splats and make sure the tile lists cover them.
+int prepare_lists(s2d_ctx* c)
+{
+    const bool scheduled = !c->lists_valid || c->rebin_interval <= 1 || c->since_rebin >= c->rebin_interval;
+    if (!scheduled) {
+        // lists are reused: verify on the device that no splat left the rectangle it was binned with
+        S2D_HIP(c, hipMemsetAsync(&c->d_status->rebin_needed, 0, sizeof(int), c->stream));
+        S2D_HIP(c, launch_project(c->d_splats, c->n, c->g, 0.0f, 1, c->d_proj, c->d_rects, c->d_counts, c->d_status,
+                                  c->stream));
+        S2D_HIP(c, hipMemcpyAsync(&c->h_status->rebin_needed, &c->d_status->rebin_needed, sizeof(int),
+                                  hipMemcpyDeviceToHost, c->stream));
+        S2D_HIP(c, hipStreamSynchronize(c->stream));
+        if (!c->h_status->rebin_needed) return S2D_OK;
+    }
+    S2D_HIP(c, launch_project(c->d_splats, c->n, c->g, c->margin, 0, c->d_proj, c->d_rects, c->d_counts, c->d_status,
+                              c->stream));
+    return rebuild_lists(c);
+}
+
+int queue_forward(s2d_ctx* c)
+{
+    if (!c->have_target) return fail(c, S2D_E_STATE, "no target image set (s2d_set_target)");
+    int rc = prepare_lists(c);
+    if (rc != S2D_OK) return rc;
+    S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->g,
+                                     (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
+    c->have_forward = true;
+    c->have_backward = false;
+    return S2D_OK;
+}
+
+int queue_backward(s2d_ctx* c)
+{
+    if (!c->have_forward) return fail(c, S2D_E_STATE, "s2d_backward needs s2d_forward on the current parameters");
+    const int slot = c->iterations % c->trace_cap;
+    S2D_HIP(c, launch_raster_backward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->d_grads,
+                                      c->d_tile_sqerr, c->g,
+                                      (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
+    S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->stream));
+    c->last_sqerr_slot = slot;
+    c->have_backward = true;
+    return S2D_OK;
+}
+
+int queue_adam(s2d_ctx* c, uint32_t flags)
+{
+    c->beta1t *= kAdamBeta1; // main.cpp:718-719
+    c->beta2t *= kAdamBeta2;
+    S2D_HIP(c, launch_adam(c->d_splats, c->d_adams, c->d_grads, c->n, c->g.W, c->g.H, c->beta1t, c->beta2t, c->lr,
+                           (flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0, c->iterations, c->d_status, c->stream));
+    c->iterations++; // main.cpp:809
+    c->since_rebin++;
+    c->have_forward = false;
+    c->have_backward = false;
+    return S2D_OK;
+}
+
+int check_status(s2d_ctx* c)
+{
+    S2D_HIP(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(DeviceStatus), hipMemcpyDeviceToHost, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->h_status->nonfinite)
+        return fail(c, S2D_E_NONFINITE, "non-finite parameter after iteration %d (the reference abort()s, main.cpp:752-785)",
+                    c->h_status->first_nonfinite_iter);
+    return S2D_OK;
+}
+
+double mse_norm(const s2d_ctx* c) { return (double)((long long)c->g.H * c->g.W * 3); }
+
+} // namespace
+
+extern "C" {
+
+int s2d_abi_version(void) { return S2D_ABI_VERSION; }
+
+int s2d_create(const s2d_config* cfg, s2d_ctx** out)
+{
+    if (!cfg || !out || cfg->struct_size != sizeof(s2d_config)) return S2D_E_INVALID;
+    *out = nullptr;
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->n_splats < 0 || cfg->width > 65536 || cfg->height > 65536)
+        return S2D_E_INVALID;
+    int rb = cfg->row_begin, re = cfg->row_end;
+    if (rb == 0 && re == 0) re = cfg->height;
+    if (rb < 0 || re > cfg->height || rb >= re || (rb % kTile) != 0) return S2D_E_INVALID;
+
+    s2d_ctx* c = new (std::nothrow) s2d_ctx();
+    if (!c) return S2D_E_NOMEM;
+    *out = c; // handed out even on failure so that s2d_last_error works; caller destroys it
+    c->cfg = *cfg;
+    c->n = cfg->n_splats;
+    c->device = cfg->device;
+    c->lr = cfg->training_rate > 0.0f ? cfg->training_rate : 0.05f; // main.cpp:715
+    c->rebin_interval = cfg->rebin_interval > 0 ? cfg->rebin_interval : 1;
+    c->margin = c->rebin_interval > 1 ? 0.3f * (float)c->rebin_interval : 0.0f;
+
+    Geometry& g = c->g;
+    g.W = cfg->width; g.H = cfg->height;
+    g.row_begin = rb; g.row_end = re;
+    g.tiles_x = (g.W + kTile - 1) / kTile;
+    g.trow0 = rb / kTile;
+    g.tiles_y = (re + kTile - 1) / kTile - g.trow0;
+    g.num_tiles = g.tiles_x * g.tiles_y;
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(c, S2D_E_HIP, "no HIP device available (%s): this library has no CPU fallback", hipGetErrorString(e));
+    if (c->device < 0 || c->device >= ndev) return fail(c, S2D_E_INVALID, "device %d out of range (%d devices)", c->device, ndev);
+    S2D_HIP(c, hipSetDevice(c->device));
+    if (cfg->stream) {
+        c->stream = (hipStream_t)cfg->stream;
+    } else {
+        S2D_HIP(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+
+    const size_t n = std::max<size_t>((size_t)c->n, 1), px = (size_t)g.W * g.H; // >= 1 so that n == 0 still has buffers
+    S2D_HIP(c, dev_alloc(&c->d_splats, n * 9));
+    S2D_HIP(c, dev_alloc(&c->d_adams, n * 18));
+    S2D_HIP(c, dev_alloc(&c->d_grads_own, n * 9));
+    c->d_grads = c->d_grads_own;
+    S2D_HIP(c, dev_alloc(&c->d_proj, n));
+    S2D_HIP(c, dev_alloc(&c->d_rects, n));
+    S2D_HIP(c, dev_alloc(&c->d_counts, n));
+    S2D_HIP(c, dev_alloc(&c->d_offsets, n));
+    S2D_HIP(c, dev_alloc(&c->d_scan_temp, scan_temp_words((int64_t)n)));
+    S2D_HIP(c, dev_alloc(&c->d_total, 4));
+    S2D_HIP(c, dev_alloc(&c->d_tile_off, (size_t)g.num_tiles + 1));
+    S2D_HIP(c, dev_alloc(&c->d_image0, px));
+    S2D_HIP(c, dev_alloc(&c->d_ref, px));
+    S2D_HIP(c, dev_alloc(&c->d_tile_sqerr, (size_t)g.num_tiles));
+    S2D_HIP(c, dev_alloc(&c->d_sqerr_trace, (size_t)c->trace_cap));
+    S2D_HIP(c, dev_alloc(&c->d_status, 1));
+    S2D_HIP(c, dev_alloc(&c->d_counters, 1));
+    S2D_HIP(c, hipHostMalloc((void**)&c->h_total, 64, hipHostMallocDefault));
+    S2D_HIP(c, hipHostMalloc((void**)&c->h_status, sizeof(DeviceStatus), hipHostMallocDefault));
+
+    S2D_HIP(c, hipMemsetAsync(c->d_splats, 0, n * 9 * sizeof(float), c->stream));
+    S2D_HIP(c, hipMemsetAsync(c->d_adams, 0, n * 18 * sizeof(float), c->stream));
+    S2D_HIP(c, hipMemsetAsync(c->d_grads_own, 0, n * 9 * sizeof(float), c->stream));
+    S2D_HIP(c, hipMemsetAsync(c->d_image0, 0, px * sizeof(float4), c->stream));
+    S2D_HIP(c, hipMemsetAsync(c->d_ref, 0, px * sizeof(float4), c->stream));
+    S2D_HIP(c, hipMemsetAsync(c->d_sqerr_trace, 0, (size_t)c->trace_cap * sizeof(double), c->stream));
+    S2D_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(PairCounters), c->stream));
+    DeviceStatus st0{0, INT_MAX, 0, 0};
+    *c->h_status = st0;
+    S2D_HIP(c, hipMemcpyAsync(c->d_status, c->h_status, sizeof(DeviceStatus), hipMemcpyHostToDevice, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    // ~16 tiles per splat at init() scales; grown on demand
+    int rc = ensure_pair_capacity(c, std::max<uint64_t>((uint64_t)n * 20, 1 << 16));
+    if (rc != S2D_OK) return rc;
+    return S2D_OK;
+}
+
+void s2d_destroy(s2d_ctx* c)
+{
+    if (!c) return;
+    if (hipSetDevice(c->device) == hipSuccess) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        void* ptrs[] = {c->d_splats, c->d_adams, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
+                        c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
+                        c->d_sort_temp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_sqerr_trace,
+                        c->d_status, c->d_counters};
+        for (void* p : ptrs)
+            if (p) (void)hipFree(p);
+        if (c->h_total) (void)hipHostFree(c->h_total);
+        if (c->h_status) (void)hipHostFree(c->h_status);
+        if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+const char* s2d_last_error(const s2d_ctx* c) { return c ? c->err : "null context"; }
+
+int s2d_set_target(s2d_ctx* c, const float* rgba32f)
+{
+    if (!c || !rgba32f) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    const size_t bytes = (size_t)c->g.W * c->g.H * sizeof(float4);
+    S2D_HIP(c, hipMemcpyAsync(c->d_ref, rgba32f, bytes, hipMemcpyHostToDevice, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    c->have_target = true;
+    c->have_forward = c->have_backward = false;
+    return S2D_OK;
+}
+
+int s2d_set_target_synthetic(s2d_ctx* c)
+{
+    if (!c) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    S2D_HIP(c, launch_synthetic_target(c->d_ref, c->g.W, c->g.H, c->stream));
+    c->have_target = true;
+    c->have_forward = c->have_backward = false;
+    return S2D_OK;
+}
+
+int s2d_init_splats(s2d_ctx* c)
+{
+    if (!c) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    S2D_HIP(c, launch_init_splats(c->d_splats, c->d_adams, c->n, c->g.W, c->g.H, c->stream));
+    if (c->n > 0) S2D_HIP(c, hipMemsetAsync(c->d_grads, 0, (size_t)c->n * 9 * sizeof(float), c->stream));
+    c->beta1t = 1.0f; // main.cpp:283-284
+    c->beta2t = 1.0f;
+    c->iterations = 0; // main.cpp:281
+    c->lists_valid = false;
+    c->have_forward = c->have_backward = false;
+    return S2D_OK;
+}
+
+int s2d_set_splats(s2d_ctx* c, const s2d_splat* splats)
+{
+    if (!c || (!splats && c->n)) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    S2D_HIP(c, hipMemcpyAsync(c->d_splats, splats, (size_t)c->n * sizeof(s2d_splat), hipMemcpyHostToDevice, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    c->lists_valid = false;
+    c->have_forward = c->have_backward = false;
+    return S2D_OK;
+}
+
+int s2d_get_splats(s2d_ctx* c, s2d_splat* splats)
+{
+    if (!c || (!splats && c->n)) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    S2D_HIP(c, hipMemcpyAsync(splats, c->d_splats, (size_t)c->n * sizeof(s2d_splat), hipMemcpyDeviceToHost, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    return S2D_OK;
+}
+
+int s2d_set_adam(s2d_ctx* c, const s2d_splat_adam* adams, float beta1t, float beta2t, int32_t iterations)
+{
+    if (!c || (!adams && c->n) || iterations < 0) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    S2D_HIP(c, hipMemcpyAsync(c->d_adams, adams, (size_t)c->n * sizeof(s2d_splat_adam), hipMemcpyHostToDevice, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    c->beta1t = beta1t;
+    c->beta2t = beta2t;
+    c->iterations = iterations;
+    return S2D_OK;
+}
+
+int s2d_get_adam(s2d_ctx* c, s2d_splat_adam* adams, float* beta1t, float* beta2t, int32_t* iterations)
+{
+    if (!c) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    if (adams) {
+        S2D_HIP(c, hipMemcpyAsync(adams, c->d_adams, (size_t)c->n * sizeof(s2d_splat_adam), hipMemcpyDeviceToHost, c->stream));
+        S2D_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    if (beta1t) *beta1t = c->beta1t;
+    if (beta2t) *beta2t = c->beta2t;
+    if (iterations) *iterations = c->iterations;
+    return S2D_OK;
+}
+
+int s2d_forward(s2d_ctx* c)
+{
+    if (!c) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    return queue_forward(c);
+}
+
+int s2d_get_image(s2d_ctx* c, float* rgba32f)
+{
+    if (!c || !rgba32f) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    const size_t bytes = (size_t)c->g.W * c->g.H * sizeof(float4);
+    S2D_HIP(c, hipMemcpyAsync(rgba32f, c->d_image0, bytes, hipMemcpyDeviceToHost, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    return S2D_OK;
+}
+
+int s2d_backward(s2d_ctx* c)
+{
+    if (!c) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    return queue_backward(c);
+}
+
+int s2d_get_grads(s2d_ctx* c, s2d_splat* dsplats)
+{
+    if (!c || (!dsplats && c->n)) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    S2D_HIP(c, hipMemcpyAsync(dsplats, c->d_grads, (size_t)c->n * sizeof(s2d_splat), hipMemcpyDeviceToHost, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    return S2D_OK;
+}
+
+int s2d_adam_step(s2d_ctx* c, uint32_t flags)
+{
+    if (!c) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    if (int rc = queue_adam(c, flags)) return rc;
+    return S2D_OK;
+}
+
+int s2d_step(s2d_ctx* c, int32_t iters, uint32_t flags, double* mse_out)
+{
+    if (!c || iters < 0) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    const double norm = mse_norm(c);
+    int done = 0;
+    while (done < iters) {
+        const int chunk = std::min(iters - done, c->trace_cap);
+        const int first_iter = c->iterations;
+        for (int k = 0; k < chunk; k++) {
+            if (int rc = queue_forward(c)) return rc;
+            if (int rc = queue_backward(c)) return rc;
+            if (int rc = queue_adam(c, flags)) return rc;
+        }
+        if (mse_out) {
+            if (int rc = s2d_get_sqerr_trace(c, first_iter, chunk, mse_out + done)) return rc;
+            for (int k = 0; k < chunk; k++) mse_out[done + k] /= norm; // main.cpp:805
+        }
+        done += chunk;
+    }
+    return check_status(c);
+}
+
+int s2d_get_mse(s2d_ctx* c, double* mse)
+{
+    if (!c || !mse) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    if (c->last_sqerr_slot < 0) return fail(c, S2D_E_STATE, "no backward pass has run yet");
+    double v = 0.0;
+    S2D_HIP(c, hipMemcpyAsync(&v, c->d_sqerr_trace + c->last_sqerr_slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    *mse = v / mse_norm(c);
+    return S2D_OK;
+}
+
+int s2d_bind_grads_device(s2d_ctx* c, void* grads_device)
+{
+    if (!c) return S2D_E_INVALID;
+    c->d_grads = grads_device ? (float*)grads_device : c->d_grads_own;
+    return S2D_OK;
+}
+
+void* s2d_grads_device_ptr(s2d_ctx* c) { return c ? (void*)c->d_grads : nullptr; }
+
+int s2d_get_sqerr_trace(s2d_ctx* c, int32_t first_iteration, int32_t count, double* out)
+{
+    if (!c || !out || count < 0 || first_iteration < 0 || count > c->trace_cap) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    int done = 0;
+    while (done < count) {
+        const int slot = (first_iteration + done) % c->trace_cap;
+        const int run = std::min(count - done, c->trace_cap - slot);
+        S2D_HIP(c, hipMemcpyAsync(out + done, c->d_sqerr_trace + slot, (size_t)run * sizeof(double),
+                                  hipMemcpyDeviceToHost, c->stream));
+        done += run;
+    }
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    return S2D_OK;
+}
+
+int s2d_synchronize(s2d_ctx* c)
+{
+    if (!c) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    return check_status(c);
+}
+
+int s2d_get_stats(s2d_ctx* c, s2d_stats* out)
+{
+    if (!c || !out) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    PairCounters pc;
+    S2D_HIP(c, hipMemcpyAsync(&pc, c->d_counters, sizeof(pc), hipMemcpyDeviceToHost, c->stream));
+    S2D_HIP(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(DeviceStatus), hipMemcpyDeviceToHost, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    std::memset(out, 0, sizeof(*out));
+    out->pairs_binned = c->pairs;
+    out->pairs_capacity = c->pair_capacity;
+    out->rebins = c->rebins;
+    out->fwd_visited = pc.fwd_visited; out->fwd_active = pc.fwd_active;
+    out->bwd_visited = pc.bwd_visited; out->bwd_active = pc.bwd_active;
+    out->fwd_staged = pc.fwd_staged; out->bwd_staged = pc.bwd_staged;
+    out->iterations = c->iterations;
+    out->first_nonfinite_iteration = c->h_status->nonfinite ? c->h_status->first_nonfinite_iter : -1;
+    return S2D_OK;
+}
+
+int s2d_debug_get_tile_lists(s2d_ctx* c, int32_t* tiles_x, int32_t* tiles_y, uint32_t* offsets,
+                             int64_t offsets_capacity, uint32_t* list, int64_t list_capacity)
+{
+    if (!c) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    if (!c->lists_valid) return fail(c, S2D_E_STATE, "tile lists not built yet (run s2d_forward)");
+    if (tiles_x) *tiles_x = c->g.tiles_x;
+    if (tiles_y) *tiles_y = c->g.tiles_y;
+    if (offsets) {
+        if (offsets_capacity < c->g.num_tiles + 1) return S2D_E_INVALID;
+        S2D_HIP(c, hipMemcpyAsync(offsets, c->d_tile_off, (size_t)(c->g.num_tiles + 1) * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, c->stream));
+    }
+    if (list) {
+        if (list_capacity < (int64_t)c->pairs) return S2D_E_INVALID;
+        S2D_HIP(c, hipMemcpyAsync(list, c->d_list, (size_t)c->pairs * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    }
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    return S2D_OK;
+}
+
+// ---- test hooks -----------------------------------------------------------------------------------
+#define S2D_HIP0(expr)                         \
+    do {                                       \
+        if ((expr) != hipSuccess) { rc = S2D_E_HIP; goto done; } \
+    } while (0)
+
+int s2d_test_sincos(int32_t device, const float* x, int32_t n, float* sin_out, float* cos_out)
+{
+    if (!x || !sin_out || !cos_out || n < 0) return S2D_E_INVALID;
+    int rc = S2D_OK;
+    float *dx = nullptr, *ds = nullptr, *dc = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(float);
+    S2D_HIP0(hipSetDevice(device));
+    S2D_HIP0(hipMalloc((void**)&dx, bytes));
+    S2D_HIP0(hipMalloc((void**)&ds, bytes));
+    S2D_HIP0(hipMalloc((void**)&dc, bytes));
+    S2D_HIP0(hipMemcpy(dx, x, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+    S2D_HIP0(launch_test_sincos(dx, n, ds, dc, nullptr));
+    S2D_HIP0(hipDeviceSynchronize());
+    S2D_HIP0(hipMemcpy(sin_out, ds, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    S2D_HIP0(hipMemcpy(cos_out, dc, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+done:
+    if (dx) (void)hipFree(dx);
+    if (ds) (void)hipFree(ds);
+    if (dc) (void)hipFree(dc);
+    return rc;
+}
+
+int s2d_test_sort_pairs(int32_t device, uint32_t* keys, uint32_t* values, int64_t n, int32_t key_bits)
+{
+    if (!keys || !values || n < 0 || key_bits < 0 || key_bits > 32) return S2D_E_INVALID;
+    int rc = S2D_OK;
+    uint32_t *k[2] = {nullptr, nullptr}, *v[2] = {nullptr, nullptr}, *temp = nullptr, *ko = nullptr, *vo = nullptr;
+    const size_t bytes = std::max<size_t>((size_t)n, 1) * sizeof(uint32_t);
+    S2D_HIP0(hipSetDevice(device));
+    for (int i = 0; i < 2; i++) {
+        S2D_HIP0(hipMalloc((void**)&k[i], bytes));
+        S2D_HIP0(hipMalloc((void**)&v[i], bytes));
+    }
+    S2D_HIP0(hipMalloc((void**)&temp, sort_temp_words(n) * sizeof(uint32_t)));
+    S2D_HIP0(hipMemcpy(k[0], keys, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    S2D_HIP0(hipMemcpy(v[0], values, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    S2D_HIP0(sort_pairs_u32(k[0], v[0], k[1], v[1], n, key_bits, temp, &ko, &vo, nullptr));
+    S2D_HIP0(hipDeviceSynchronize());
+    S2D_HIP0(hipMemcpy(keys, ko, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    S2D_HIP0(hipMemcpy(values, vo, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+done:
+    for (int i = 0; i < 2; i++) {
+        if (k[i]) (void)hipFree(k[i]);
+        if (v[i]) (void)hipFree(v[i]);
+    }
+    if (temp) (void)hipFree(temp);
+    return rc;
+}
+
+int s2d_test_exclusive_scan(int32_t device, uint32_t* data, int64_t n, uint64_t* total)
+{
+    if (!data || n < 0) return S2D_E_INVALID;
+    int rc = S2D_OK;
+    uint32_t *d = nullptr, *temp = nullptr, *tot = nullptr, htot = 0;
+    S2D_HIP0(hipSetDevice(device));
+    S2D_HIP0(hipMalloc((void**)&d, std::max<size_t>((size_t)n, 1) * sizeof(uint32_t)));
+    S2D_HIP0(hipMalloc((void**)&temp, scan_temp_words(n) * sizeof(uint32_t)));
+    S2D_HIP0(hipMalloc((void**)&tot, sizeof(uint32_t)));
+    S2D_HIP0(hipMemcpy(d, data, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    S2D_HIP0(exclusive_scan_u32(d, d, n, temp, tot, nullptr));
+    S2D_HIP0(hipDeviceSynchronize());
+    S2D_HIP0(hipMemcpy(data, d, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    S2D_HIP0(hipMemcpy(&htot, tot, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (total) *total = htot;
+done:
+    if (d) (void)hipFree(d);
+    if (temp) (void)hipFree(temp);
+    if (tot) (void)hipFree(tot);
+    return rc;
+}
+
+} // extern "C"

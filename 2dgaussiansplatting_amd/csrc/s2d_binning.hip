@@ -1,0 +1,135 @@
+// s2d_binning.hip -- projection of the splats and construction of the per-tile lists.
+//
+// project_kernel   1 thread / splat: covariance, inverse, row range (main.cpp:423-436, 489-491 ==
+//                  556-575) -> 64-byte ProjRec; conservative tile rectangle -> TileRect + pair count.
+// emit_kernel      1 thread / splat: writes its (tile, splat) pairs at the scanned offset, in splat
+//                  order, so the stable sort by tile leaves every tile's list in index order.
+// tile_offsets     boundaries of the sorted key array -> tile_off[0..tiles].
+#include "s2d_device.h"
+
+namespace s2d {
+
+__device__ __forceinline__ float as_f(int v) { return __int_as_float(v); }
+
+// Conservative tile rectangle (local to the slab) of a projected splat, inflated by `margin` pixels.
+// Columns: the exact per-row ranges (row_range) lie within pos_x +- hx up to rounding and the
+// truncation toward zero of negative values; a 1-pixel skirt covers both.
+__device__ __forceinline__ bool tile_rect_of(const Projected& p, const Geometry& g, float margin, TileRect* r)
+{
+    const int m = (int)margin;
+    // rows: [begY, endY] from the reference, clipped to the slab
+    long long y0 = (long long)p.begY - m, y1 = (long long)p.endY + m;
+    if (p.begY == (int)0x80000000u || p.endY == (int)0x80000000u) return false; // NaN / out of range
+    if (y0 < g.row_begin) y0 = g.row_begin;
+    if (y1 > g.row_end - 1) y1 = g.row_end - 1;
+    if (y0 > y1) return false;
+    float xlo = p.pos_x - p.hx - 1.0f - margin;
+    float xhi = p.pos_x + p.hx + 1.0f + margin;
+    if (!(xlo <= xhi)) return false; // NaN
+    if (xhi < 0.0f || xlo > (float)(g.W - 1)) return false;
+    xlo = fmaxf(xlo, 0.0f);
+    xhi = fminf(xhi, (float)(g.W - 1));
+    r->tx0 = (uint16_t)((int)xlo >> 4);
+    r->tx1 = (uint16_t)((int)xhi >> 4);
+    r->ty0 = (uint16_t)(((int)y0 >> 4) - g.trow0);
+    r->ty1 = (uint16_t)(((int)y1 >> 4) - g.trow0);
+    return true;
+}
+
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ splats, int n, Geometry g,
+                                                      float margin, int mode, ProjRec* __restrict__ proj,
+                                                      TileRect* __restrict__ rects, uint32_t* __restrict__ counts,
+                                                      DeviceStatus* __restrict__ status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* sp = splats + (size_t)i * 9;
+    Splat s;
+    s.pos_x = sp[0]; s.pos_y = sp[1]; s.sx = sp[2]; s.sy = sp[3]; s.rot = sp[4];
+    s.col_r = sp[5]; s.col_g = sp[6]; s.col_b = sp[7]; s.opacity = sp[8];
+    const Projected p = project(s);
+    ProjRec rec;
+    rec.q0 = make_float4(p.pos_x, p.pos_y, p.a, p.b);
+    rec.q1 = make_float4(p.d, p.col_r, p.col_g, p.col_b);
+    rec.q2 = make_float4(p.opacity, as_f(p.begY), as_f(p.endY), p.cosT);
+    rec.q3 = make_float4(p.sinT, p.sx, p.sy, p.hx);
+    proj[i] = rec;
+
+    TileRect r;
+    r.tx0 = 1; r.tx1 = 0; r.ty0 = 1; r.ty1 = 0;
+    if (mode == 0) {
+        uint32_t cnt = 0;
+        if (tile_rect_of(p, g, margin, &r)) cnt = (uint32_t)(r.tx1 - r.tx0 + 1) * (uint32_t)(r.ty1 - r.ty0 + 1);
+        else { r.tx0 = 1; r.tx1 = 0; r.ty0 = 1; r.ty1 = 0; }
+        rects[i] = r;
+        counts[i] = cnt;
+    } else {
+        // the exact rectangle (margin 0) must still lie inside the rectangle the lists were built from
+        if (tile_rect_of(p, g, 0.0f, &r)) {
+            const TileRect b = rects[i];
+            const bool inside = b.tx0 <= b.tx1 && r.tx0 >= b.tx0 && r.tx1 <= b.tx1 && r.ty0 >= b.ty0 && r.ty1 <= b.ty1;
+            if (!inside) atomicOr(&status->rebin_needed, 1);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void emit_kernel(const TileRect* __restrict__ rects,
+                                                   const uint32_t* __restrict__ offsets, int n, int tiles_x,
+                                                   uint32_t* __restrict__ keys, uint32_t* __restrict__ vals,
+                                                   uint32_t capacity)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const TileRect r = rects[i];
+    if (r.tx0 > r.tx1) return;
+    uint32_t o = offsets[i];
+    for (uint32_t ty = r.ty0; ty <= r.ty1; ty++)
+        for (uint32_t tx = r.tx0; tx <= r.tx1; tx++) {
+            if (o < capacity) {
+                keys[o] = ty * (uint32_t)tiles_x + tx;
+                vals[o] = (uint32_t)i;
+            }
+            o++;
+        }
+}
+
+// tile_off[t] = first position p with sorted_keys[p] >= t; tile_off[num_tiles] = num_pairs.
+__global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __restrict__ sorted_keys,
+                                                           uint32_t num_pairs, int num_tiles,
+                                                           uint32_t* __restrict__ tile_off)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > num_pairs) return;
+    const int cur = (p < num_pairs) ? (int)sorted_keys[p] : num_tiles;
+    const int prev = (p > 0) ? (int)sorted_keys[p - 1] : -1;
+    for (int t = prev + 1; t <= cur; t++) tile_off[t] = p;
+}
+
+hipError_t launch_project(const float* splats, int n, Geometry g, float margin, int mode, ProjRec* proj,
+                          TileRect* rects, uint32_t* counts, DeviceStatus* status, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(project_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, n, g, margin, mode, proj,
+                       rects, counts, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit_pairs(const TileRect* rects, const uint32_t* offsets, int n, Geometry g,
+                             uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rects, offsets, n, g.tiles_x, keys,
+                       vals, capacity);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, int num_tiles,
+                               uint32_t* tile_off, hipStream_t stream)
+{
+    const uint32_t threads = num_pairs + 1;
+    hipLaunchKernelGGL(tile_offsets_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, sorted_keys, num_pairs,
+                       num_tiles, tile_off);
+    return hipGetLastError();
+}
+
+} // namespace s2d

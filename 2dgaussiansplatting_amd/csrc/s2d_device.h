@@ -1,0 +1,97 @@
+// s2d_device.h -- internal declarations shared by the HIP translation units.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "s2d_math.h"
+
+namespace s2d {
+
+// ---- data layout in HBM -----------------------------------------------------------------------
+// Projected splat: what the raster kernels need per list entry, one 64-byte record (4 x float4)
+// so that a list entry is staged with four 16-byte loads from one cache line.
+//   q0 = (pos_x, pos_y, a, b)          a,b,d = inverse covariance (b == c bit for bit)
+//   q1 = (d, col_r, col_g, col_b)
+//   q2 = (opacity, bits(begY), bits(endY), cosT)
+//   q3 = (sinT, sx, sy, hx)
+struct alignas(16) ProjRec {
+    float4 q0, q1, q2, q3;
+};
+static_assert(sizeof(ProjRec) == 64, "ProjRec must be 64 bytes");
+
+// Inclusive tile rectangle of a splat, in tile units LOCAL to the context's slab; empty when n == 0.
+struct TileRect {
+    uint16_t tx0, tx1, ty0, ty1;
+};
+
+struct Geometry {
+    int W, H;           // image size
+    int row_begin;      // slab [row_begin, row_end) in pixel rows; row_begin % 16 == 0
+    int row_end;
+    int tiles_x;        // ceil(W / 16)
+    int trow0;          // row_begin / 16: first global tile row of the slab
+    int tiles_y;        // tile rows in the slab
+    int num_tiles;      // tiles_x * tiles_y
+};
+
+struct PairCounters {
+    unsigned long long fwd_visited, fwd_active, bwd_visited, bwd_active, fwd_staged, bwd_staged;
+};
+
+// Device-resident status word(s), written by kernels, read by the host at synchronisation points.
+struct DeviceStatus {
+    int nonfinite;            // 1 once a checked parameter became non-finite (main.cpp:752-785)
+    int first_nonfinite_iter; // iteration at which that first happened (INT_MAX if never)
+    int rebin_needed;         // a splat's exact tile rectangle left its binned rectangle
+    int pad;
+};
+
+constexpr int kRasterBatch = 64;       // list entries staged in LDS per batch
+constexpr int kSortItemsPerThread = 16;
+constexpr int kSortBlock = 256;
+constexpr int kSortItemsPerBlock = kSortBlock * kSortItemsPerThread; // 4096
+constexpr int kScanItemsPerThread = 8;
+constexpr int kScanBlock = 256;
+constexpr int kScanItemsPerBlock = kScanBlock * kScanItemsPerThread; // 2048
+
+// ---- launchers (each queues kernels on `stream`, never synchronises) ------------------------------
+// scan / sort (s2d_scan_sort.hip)
+size_t scan_temp_words(int64_t n);
+// exclusive prefix sum of in[0..n) into out[0..n) (may alias); *total_dev (device) receives the sum.
+hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* temp, uint32_t* total_dev,
+                              hipStream_t stream);
+size_t sort_temp_words(int64_t n);
+// Stable LSD radix sort by the low key_bits of keys.  Result pointers (one of the two buffers each) are
+// returned through keys_out / vals_out.
+hipError_t sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int64_t n,
+                          int key_bits, uint32_t* temp, uint32_t** keys_out, uint32_t** vals_out,
+                          hipStream_t stream);
+
+// binning (s2d_binning.hip)
+// Projects every splat; mode 0: also writes rects[] (inflated by `margin` pixels) and counts[];
+// mode 1: checks that the exact rectangle lies inside rects[] and raises status->rebin_needed otherwise.
+hipError_t launch_project(const float* splats, int n, Geometry g, float margin, int mode, ProjRec* proj,
+                          TileRect* rects, uint32_t* counts, DeviceStatus* status, hipStream_t stream);
+hipError_t launch_emit_pairs(const TileRect* rects, const uint32_t* offsets, int n, Geometry g,
+                             uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream);
+hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, int num_tiles,
+                               uint32_t* tile_off, hipStream_t stream);
+
+// raster (s2d_raster.hip)
+hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
+                                 float4* image0, Geometry g, PairCounters* counters, hipStream_t stream);
+hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
+                                  const float4* image0, const float4* image_ref, float* grads,
+                                  double* tile_sqerr, Geometry g, PairCounters* counters, hipStream_t stream);
+// Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
+hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, hipStream_t stream);
+
+// optimiser / init (s2d_optim.hip)
+hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream);
+hipError_t launch_adam(float* splats, float* adams, float* grads, int n, int W, int H, float beta1t, float beta2t,
+                       float lr, int optimize_opacity, int iteration, DeviceStatus* status, hipStream_t stream);
+hipError_t launch_synthetic_target(float4* image_ref, int W, int H, hipStream_t stream);
+hipError_t launch_test_sincos(const float* x, int n, float* s, float* c, hipStream_t stream);
+
+} // namespace s2d

@@ -1,0 +1,118 @@
+// s2d_optim.hip -- init(), the Adam step with constraints and finite guard, and small utilities.
+#include "s2d_device.h"
+
+namespace s2d {
+
+// init(), main.cpp:280-305: one thread per splat; Adam state zeroed (main.cpp:285-286).
+__global__ __launch_bounds__(256) void init_splats_kernel(float* __restrict__ splats, float* __restrict__ adams, int n,
+                                                          int W, int H)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Splat s = init_splat((uint32_t)i, W, H);
+    float* o = splats + (size_t)i * 9;
+    o[0] = s.pos_x; o[1] = s.pos_y; o[2] = s.sx; o[3] = s.sy; o[4] = s.rot;
+    o[5] = s.col_r; o[6] = s.col_g; o[7] = s.col_b; o[8] = s.opacity;
+    float* a = adams + (size_t)i * 18;
+#pragma unroll
+    for (int k = 0; k < 18; k++) a[k] = 0.0f;
+}
+
+__device__ __forceinline__ bool finite_f32(float x) { return (f32_bits(x) & 0x7f800000u) != 0x7f800000u; }
+
+// main.cpp:721-785 for one splat per thread.  The scalar order of Splat (pos.xy, sx, sy, rot, color.rgb,
+// opacity) and of SplatAdam (pos[2], sx, sy, rot, color[3], opacity) is the same, so scalar k of the splat
+// pairs with Adam slot k.  The nine updates are independent, so the reference's update order (color, pos,
+// sx, sy, rot, opacity; main.cpp:723-738) does not matter.  Also re-zeroes the gradient record
+// (main.cpp:550 value-initialises dSplats every iteration).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, float* __restrict__ adams,
+                                                   float* __restrict__ grads, int n, int W, int H, float beta1t,
+                                                   float beta2t, float lr, int optimize_opacity, int iteration,
+                                                   DeviceStatus* __restrict__ status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float* sp = splats + (size_t)i * 9;
+    float* ad = adams + (size_t)i * 18;
+    float* gr = grads + (size_t)i * 9;
+    float v[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        v[k] = sp[k];
+        if (k < 8 || optimize_opacity) { // main.cpp:735-738
+            float m_m = ad[2 * k], m_v = ad[2 * k + 1];
+            v[k] = adam_optimize(m_m, m_v, v[k], gr[k], lr, beta1t, beta2t);
+            ad[2 * k] = m_m;
+            ad[2 * k + 1] = m_v;
+        }
+        gr[k] = 0.0f;
+    }
+    // constraints, main.cpp:741-749
+    v[0] = glm_clamp(v[0], 0.0f, (float)W - 1.0f);
+    v[1] = glm_clamp(v[1], 0.0f, (float)H - 1.0f);
+    v[2] = glm_clamp(v[2], 1.0f, 1024.0f);
+    v[3] = glm_clamp(v[3], 1.0f, 1024.0f);
+    v[5] = glm_clamp(v[5], 0.0f, 1.0f);
+    v[6] = glm_clamp(v[6], 0.0f, 1.0f);
+    v[7] = glm_clamp(v[7], 0.0f, 1.0f);
+    v[8] = glm_clamp(v[8], 0.1f, 1.0f);
+#pragma unroll
+    for (int k = 0; k < 9; k++) sp[k] = v[k];
+    // finite guard, main.cpp:752-785: color.xyz, sx, sy, rot, pos.x (pos.y and opacity are not checked)
+    const bool ok = finite_f32(v[5]) && finite_f32(v[6]) && finite_f32(v[7]) && finite_f32(v[2]) &&
+                    finite_f32(v[3]) && finite_f32(v[4]) && finite_f32(v[0]);
+    if (!ok) {
+        atomicOr(&status->nonfinite, 1);
+        atomicMin(&status->first_nonfinite_iter, iteration);
+    }
+}
+
+// ref(x,y) = (x/W, 1 - x/W, y/H, 1): main.cpp:261-267's commented generator plus a blue ramp.
+__global__ __launch_bounds__(256) void synthetic_target_kernel(float4* __restrict__ image_ref, int W, int H)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y = blockIdx.y;
+    if (x >= W || y >= H) return;
+    const float fx = (float)x / (float)W;
+    image_ref[(size_t)y * W + x] = make_float4(fx, 1.0f - fx, (float)y / (float)H, 1.0f);
+}
+
+__global__ __launch_bounds__(256) void test_sincos_kernel(const float* __restrict__ x, int n, float* __restrict__ s,
+                                                          float* __restrict__ c)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    s[i] = sinf_ref(x[i]);
+    c[i] = cosf_ref(x[i]);
+}
+
+hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(init_splats_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, n, W, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_adam(float* splats, float* adams, float* grads, int n, int W, int H, float beta1t, float beta2t,
+                       float lr, int optimize_opacity, int iteration, DeviceStatus* status, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, n, W, H, beta1t,
+                       beta2t, lr, optimize_opacity, iteration, status);
+    return hipGetLastError();
+}
+
+hipError_t launch_synthetic_target(float4* image_ref, int W, int H, hipStream_t stream)
+{
+    hipLaunchKernelGGL(synthetic_target_kernel, dim3((W + 255) / 256, H), dim3(256), 0, stream, image_ref, W, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_test_sincos(const float* x, int n, float* s, float* c, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(test_sincos_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, n, s, c);
+    return hipGetLastError();
+}
+
+} // namespace s2d

@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training iterations / second (forward + backward + Adam + MSE) of 2D Gaussian
+splatting on a 4096x4096 synthetic image with 1,000,000 Gaussians (BASELINE.json metric / configs[3]).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One process per GPU.  The image is split into N row slabs (whole tile rows); splats and Adam state are
+replicated; per iteration each rank rasterises its slab forward and backward, the N x 9 fp32 gradient
+array is all-reduced over RCCL/xGMI (the only exchange), and every rank applies the identical Adam step.
+The total work is fixed as N grows ("strong" scaling).  Prints ONE JSON line on rank 0.
+
+PyTorch is plumbing here (device memory for the all-reduce buffer, streams, torch.distributed); all
+compute is the hand-written HIP library behind include/splat2d.h.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def slab_rows(H, rank, world):
+    tile_rows = (H + 15) // 16
+    t0 = tile_rows * rank // world
+    t1 = tile_rows * (rank + 1) // world
+    return t0 * 16, min(t1 * 16, H)
+
+
+def host_cores():
+    """CPU cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.999)))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
+def cpu_baseline(W, H, n, threads):
+    """The oracle (a CPU restatement of the reference loop: kind "port"), timed on this box's host cores on
+    a bounded sample: ONE iteration of the same workload, forward/backward split over `threads` row slabs."""
+    import numpy as np
+    import oracle_lib as O
+    tgt = O.synthetic_target(W, H)
+    o = O.OracleTrainer(tgt, n)
+    t0 = time.perf_counter()
+    o.step(threads=threads)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
+            "sample": "1 iteration of the same %dx%d / %d-Gaussian workload (oracle/s2d_oracle.c, gcc -O2 "
+                      "-ffp-contract=off, forward+backward over %d row-slab threads, Adam+MSE single thread); "
+                      "%.2f s" % (W, H, n, threads, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--width", type=int, default=4096)
+    ap.add_argument("--height", type=int, default=4096)
+    ap.add_argument("--splats", type=int, default=1_000_000)
+    ap.add_argument("--rebin-interval", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    S2D = importlib.import_module("2dgaussiansplatting_amd")
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: the trainer has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H, n = args.width, args.height, args.splats
+    r0, r1 = slab_rows(H, rank, world)
+    # a real (non-default) stream: its handle goes into the C ABI, so the library's kernels, the RCCL
+    # all-reduce and the timing events below are all ordered on the same HIP stream
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    grads = torch.zeros(n * 9, dtype=torch.float32, device="cuda")
+    t = S2D.Trainer(W, H, n, device=local_rank, row_begin=r0, row_end=r1,
+                    rebin_interval=args.rebin_interval, stream=stream.cuda_stream)
+    t.bind_grads(grads.data_ptr())
+    t.set_target_synthetic()
+    t.init()
+
+    def one_step(ev=None):
+        t.forward()
+        if ev is not None:
+            ev[0].record(stream)
+        t.backward()
+        if ev is not None:
+            ev[1].record(stream)
+        if dist is not None:
+            dist.all_reduce(grads)  # sum of the per-slab partial gradients, fp32, in place
+        t.adam_step()
+
+    for _ in range(args.warmup):
+        one_step()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(events[k])
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    t.synchronize()  # raises if a parameter went non-finite
+
+    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    first = t.stats()["iterations"] - args.steps
+    sq = torch.from_numpy(t.sqerr_trace(first, args.steps)).cuda()
+    bwd_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)], dtype=torch.float64, device="cuda")
+    if dist is not None:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(sq)
+        dist.all_reduce(bwd_ms, op=dist.ReduceOp.MAX)
+    dt = float(dt_t.item())
+    mse_last = float(sq[-1].item()) / (H * W * 3) if args.steps else float("nan")
+    stats = t.stats()
+
+    if rank == 0:
+        its = args.steps / dt
+        # dominant kernel: raster_backward.  Algorithmic bytes per launch: per pixel of the
+        # slab it reads the framebuffer (16 B) and the target (16 B); per splat it reads the projected record
+        # once (64 B) and writes the 9 gradient floats once (36 B).
+        bwd_bytes = 32.0 * W * (r1 - r0) + (64.0 + 36.0) * n
+        bwd_s = float(bwd_ms.item()) * 1e-3
+        achieved = bwd_bytes / bwd_s / 1e9 if bwd_s > 0 else 0.0
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("raster_backward_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "train iters/sec (fwd+bwd+Adam)",
+            "value": its,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / max(args.steps, 1),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic target ref(x,y)=(x/W,1-x/W,y/H); splats from the reference's init() seeds",
+            "config": {"workload": "%dx%d synthetic RGB, %d Gaussians, fp32 (BASELINE.json configs[3])" % (W, H, n),
+                       "width": W, "height": H, "n_splats": n,
+                       "parallelism": "rowslab%d%s" % (world, "+rccl-allreduce-grads" if world > 1 else ""),
+                       "rebin_interval": args.rebin_interval},
+            "mse_last": mse_last,
+            "psnr_db_last": (10.0 * float(np.log10(255.0 ** 2 / mse_last)) if mse_last > 0 else None),
+            "iterations_total": stats["iterations"],
+            "pairs_binned_rank0": stats["pairs_binned"],
+            "rebins_rank0": stats["rebins"],
+            "roofline": {"bound": "hbm", "kernel": "raster_backward_kernel", "achieved": achieved, "peak": 8000.0,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "kernel_ms": float(bwd_ms.item()), "algorithmic_bytes_per_launch": bwd_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or host_cores()
+            out["cpu_baseline"] = cpu_baseline(W, H, n, threads)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    t.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

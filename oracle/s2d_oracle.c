@@ -198,10 +198,12 @@ void s2do_forward_rows(const s2do_splat* splats, int n, int W, int H, int y0, in
     if (counters) { counters->visited += visited; counters->active += active; }
 }
 
-/* main.cpp:548-712, rows [y0,y1) */
-void s2do_backward_rows(const s2do_splat* splats, int n, int W, int H, int y0, int y1,
-                        const float* image0, const float* image_ref, float* image1,
-                        s2do_splat* dsplats, s2do_counters* counters)
+/* main.cpp:548-712, rows [y0,y1).  STATS (compile-time constant after inlining) additionally accumulates
+ * every fp32 contribution into double sums (dsum: the same terms summed without fp32 rounding) and their
+ * absolute values (dabs: the scale against which a summation-order difference has to be judged). */
+static inline __attribute__((always_inline)) void backward_rows_impl(
+    const s2do_splat* splats, int n, int W, int H, int y0, int y1, const float* image0, const float* image_ref,
+    float* image1, s2do_splat* dsplats, s2do_counters* counters, const int STATS, double* dsum, double* dabs)
 {
     uint64_t visited = 0, active = 0;
     if (y0 < 0) y0 = 0;
@@ -291,12 +293,38 @@ void s2do_backward_rows(const s2do_splat* splats, int n, int W, int H, int y0, i
 
                     float dalpha_do = G; /* 703-704 */
                     dS->opacity += dL_dalpha_rgb * dalpha_do;
+
+                    if (STATS) {
+                        const float t[9] = { dL_dalpha_rgb * dalpha_dx, dL_dalpha_rgb * dalpha_dy,
+                                             dL_dalpha_rgb * dalpha_dsx, dL_dalpha_rgb * dalpha_dsy,
+                                             (dL_dalpha_x + dL_dalpha_y + dL_dalpha_z) * dalpha_dtheta,
+                                             dL_dC_x * (alpha * T), dL_dC_y * (alpha * T), dL_dC_z * (alpha * T),
+                                             dL_dalpha_rgb * dalpha_do };
+                        for (int k = 0; k < 9; k++) {
+                            dsum[(size_t)i * 9 + k] += (double)t[k];
+                            dabs[(size_t)i * 9 + k] += fabs((double)t[k]);
+                        }
+                    }
                 }
                 color[3] *= (1.0f - alpha); /* 707 */
             }
         }
     }
     if (counters) { counters->visited += visited; counters->active += active; }
+}
+
+void s2do_backward_rows(const s2do_splat* splats, int n, int W, int H, int y0, int y1,
+                        const float* image0, const float* image_ref, float* image1,
+                        s2do_splat* dsplats, s2do_counters* counters)
+{
+    backward_rows_impl(splats, n, W, H, y0, y1, image0, image_ref, image1, dsplats, counters, 0, NULL, NULL);
+}
+
+void s2do_backward_rows_stats(const s2do_splat* splats, int n, int W, int H, int y0, int y1,
+                              const float* image0, const float* image_ref, float* image1,
+                              s2do_splat* dsplats, double* dsum, double* dabs)
+{
+    backward_rows_impl(splats, n, W, H, y0, y1, image0, image_ref, image1, dsplats, NULL, 1, dsum, dabs);
 }
 
 /* main.cpp:144-156.  `sqrt` at :155 is unqualified: under g++/clang++ on Linux (where

@@ -68,6 +68,13 @@ void s2do_backward_rows(const s2do_splat* splats, int n, int W, int H, int y0, i
                         const float* image0, const float* image_ref, float* image1,
                         s2do_splat* dsplats, s2do_counters* counters);
 
+/* Same pass; additionally accumulates (into caller-zeroed n*9 doubles, record order) dsum = the sum of the
+ * SAME fp32 per-pixel contributions carried in double, and dabs = the sum of their absolute values.  Used by
+ * the parity tests to judge fp32 summation-order differences against the conditioning of each sum. */
+void s2do_backward_rows_stats(const s2do_splat* splats, int n, int W, int H, int y0, int y1,
+                              const float* image0, const float* image_ref, float* image1,
+                              s2do_splat* dsplats, double* dsum, double* dabs);
+
 /* main.cpp:714-785.  Multiplies *beta1t, *beta2t first (718-719), applies the nine
  * scalar Adam updates (opacity only if optimize_opacity), clamps, then the finite
  * guard.  Returns 0, or 1 where the reference would abort() (752-785). */

@@ -36,6 +36,7 @@ def lib():
     L.s2do_init.argtypes = [vp, vp, i, i, i]
     L.s2do_forward_rows.argtypes = [vp, i, i, i, i, i, vp, vp]
     L.s2do_backward_rows.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, vp]
+    L.s2do_backward_rows_stats.argtypes = [vp, i, i, i, i, i, vp, vp, vp, vp, vp, vp]
     L.s2do_adam_step.argtypes = [vp, vp, vp, i, i, i, vp, vp, i, f]
     L.s2do_adam_step.restype = i
     L.s2do_sqerr_rows.argtypes = [vp, vp, i, i, i, i]
@@ -128,6 +129,15 @@ class OracleTrainer:
                                   _p(self.ref), _p(self.image1), _p(self.dsplats),
                                   C.byref(counters) if counters is not None else None)
         return self.dsplats
+
+    def backward_stats(self):
+        """Backward pass + (dsum, dabs): the fp32 contributions summed in double, and the sum of their magnitudes."""
+        self.dsplats[:] = 0
+        dsum = np.zeros((self.n, 9), dtype=np.float64)
+        dabs = np.zeros((self.n, 9), dtype=np.float64)
+        self.L.s2do_backward_rows_stats(_p(self.splats), self.n, self.W, self.H, 0, self.H, _p(self.image0),
+                                        _p(self.ref), _p(self.image1), _p(self.dsplats), _p(dsum), _p(dabs))
+        return self.dsplats, dsum, dabs
 
     def adam(self, lr=0.05):
         return self.L.s2do_adam_step(_p(self.splats), _p(self.adams), _p(self.dsplats), self.n, self.W, self.H,
