@@ -46,6 +46,7 @@ class _Stats(C.Structure):
     _fields_ = [("pairs_binned", C.c_uint64), ("pairs_capacity", C.c_uint64), ("rebins", C.c_uint64),
                 ("fwd_visited", C.c_uint64), ("fwd_active", C.c_uint64), ("bwd_visited", C.c_uint64),
                 ("bwd_active", C.c_uint64), ("fwd_staged", C.c_uint64), ("bwd_staged", C.c_uint64),
+                ("fwd_wave_execs", C.c_uint64), ("bwd_wave_execs", C.c_uint64),
                 ("iterations", C.c_int32), ("first_nonfinite_iteration", C.c_int32)]
 
 

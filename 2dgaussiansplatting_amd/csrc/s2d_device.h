@@ -36,7 +36,8 @@ struct Geometry {
 };
 
 struct PairCounters {
-    unsigned long long fwd_visited, fwd_active, bwd_visited, bwd_active, fwd_staged, bwd_staged;
+    unsigned long long fwd_visited, fwd_active, bwd_visited, bwd_active, fwd_staged, bwd_staged, fwd_wave_execs,
+        bwd_wave_execs;
 };
 
 // Device-resident status word(s), written by kernels, read by the host at synchronisation points.

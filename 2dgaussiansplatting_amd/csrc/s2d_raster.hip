@@ -16,8 +16,8 @@
 // Forward arithmetic is the reference's, operation for operation (-ffp-contract=off), so the
 // framebuffer is bit-identical to the oracle's.  The backward pass recomputes T and the running
 // colour the same way, then reduces each splat's nine partial gradients over the wave with DPP,
-// over the four waves with LDS float atomics, and issues one global float-atomic burst per
-// (tile, splat) into the N x 9 gradient array.
+// over the four waves through per-wave LDS slots (plain stores, fixed order), and issues one global
+// float-atomic burst per (tile, splat) into the N x 9 gradient array.
 #include "s2d_device.h"
 
 namespace s2d {
@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
 
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, T = 1.0f;       // main.cpp:414: (0,0,0,1)
     bool alive = inside;
-    unsigned long long n_vis = 0, n_act = 0, n_staged = 0;
+    unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0;
 
     const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
     const int se = tid >> 2, sub = tid & 3;
@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                 const unsigned long long wm = wave_uniform_u64(s_mask[e * 4 + w]);
                 if (COUNT) n_vis += (wm >> lane) & 1ull;
                 if ((wm & alive_mask) == 0ull) continue;
+                if (COUNT) n_exec += (lane == 0);
                 if (((wm >> lane) & 1ull) && alive) { // main.cpp:511-521
                     const float4 q0 = s_q0[e], q1 = s_q1[e];
                     float vx, vy;
@@ -129,27 +130,43 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
         atomicAdd(&counters->fwd_visited, n_vis);
         atomicAdd(&counters->fwd_active, n_act);
         if (tid == 0) atomicAdd(&counters->fwd_staged, n_staged);
+        if (lane == 0) atomicAdd(&counters->fwd_wave_execs, n_exec);
     }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// wave-wide sum by DPP: after the six steps lane 63 holds the sum of all 64 lanes.
+// Wave-wide sums of nine values by DPP: afterwards lane 63 holds the nine totals.
+// Six steps per value: xor-1 and xor-2 inside each quad, half-mirror and mirror inside each row of 16
+// lanes (every lane of a row then holds the row's sum), row_bcast15 into rows 1 and 3, row_bcast31 into
+// rows 2 and 3.  Written as ONE asm block in step-major order: hipcc packs the source-level adds into
+// v_pk_add_f32, which cannot carry a DPP modifier (3 instructions per step instead of 1), and in this order
+// every register is read again only nine instructions after it was written, so the DPP read-after-VALU-write
+// wait states are covered without padding (the leading s_nop covers the producers of the inputs).
+// All 64 lanes are active here (wave-uniform control flow).
 // ---------------------------------------------------------------------------------------------------
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_get(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
+#define S2D_DPP9(ctrl)                                  \
+    "v_add_f32_dpp %0, %0, %0 " ctrl "\n"               \
+    "v_add_f32_dpp %1, %1, %1 " ctrl "\n"               \
+    "v_add_f32_dpp %2, %2, %2 " ctrl "\n"               \
+    "v_add_f32_dpp %3, %3, %3 " ctrl "\n"               \
+    "v_add_f32_dpp %4, %4, %4 " ctrl "\n"               \
+    "v_add_f32_dpp %5, %5, %5 " ctrl "\n"               \
+    "v_add_f32_dpp %6, %6, %6 " ctrl "\n"               \
+    "v_add_f32_dpp %7, %7, %7 " ctrl "\n"               \
+    "v_add_f32_dpp %8, %8, %8 " ctrl "\n"
 
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
+__device__ __forceinline__ void wave_sum9_to_lane63(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5,
+                                                    float& a6, float& a7, float& a8)
 {
-    v += dpp_get<0xB1, 0xF>(v);  // quad_perm [1,0,3,2]
-    v += dpp_get<0x4E, 0xF>(v);  // quad_perm [2,3,0,1]
-    v += dpp_get<0x141, 0xF>(v); // row_half_mirror
-    v += dpp_get<0x140, 0xF>(v); // row_mirror: every lane of a row now holds the row's sum
-    v += dpp_get<0x142, 0xA>(v); // row_bcast15 into rows 1 and 3
-    v += dpp_get<0x143, 0xC>(v); // row_bcast31 into rows 2 and 3
-    return v;
+    asm volatile("s_nop 1\n"
+                 S2D_DPP9("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
+                 S2D_DPP9("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
+                 S2D_DPP9("row_half_mirror row_mask:0xf bank_mask:0xf")
+                 S2D_DPP9("row_mirror row_mask:0xf bank_mask:0xf")
+                 S2D_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 S2D_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 1\n"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -172,7 +189,10 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     __shared__ float s_op[B];
     __shared__ unsigned long long s_mask[B * 4];
     __shared__ uint32_t s_idx[2][B];
-    __shared__ float s_acc[B * 9];
+    // per-wave partial gradients of the batch: written once per (wave, entry) by lane 63 with plain stores,
+    // summed over the 4 waves in a fixed order by the flush.  12 floats per slot keep float4 stores aligned.
+    __shared__ float4 s_part[4][B][3];
+    __shared__ unsigned long long s_touched[4]; // bit e: wave w wrote slot e in this batch
     __shared__ double s_red[4];
 
     const int tile = tile_of_block(blockIdx.x, g.num_tiles);
@@ -200,13 +220,12 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         for (int d = 32; d >= 1; d >>= 1) e2 += __shfl_down(e2, d, 64);
         if (lane == 0) s_red[w] = e2;
     }
-    for (int i = tid; i < B * 9; i += 256) s_acc[i] = 0.0f;
     __syncthreads();
     if (tid == 0) tile_sqerr[tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
 
     float cr = 0.0f, cg = 0.0f, cb = 0.0f, T = 1.0f; // image1 = (0,0,0,1), main.cpp:549
     bool alive = inside;
-    unsigned long long n_vis = 0, n_act = 0, n_staged = 0;
+    unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0;
 
     const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
     const int se = tid >> 2, sub = tid & 3;
@@ -235,11 +254,14 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         __syncthreads();
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
         unsigned long long alive_mask = __ballot(alive);
+        unsigned long long touched = 0ull;
         if (alive_mask != 0ull || COUNT) {
             for (int e = 0; e < cnt; e++) {
                 const unsigned long long wm = wave_uniform_u64(s_mask[e * 4 + w]);
                 if (COUNT) n_vis += (wm >> lane) & 1ull;
                 if ((wm & alive_mask) == 0ull) continue;
+                touched |= 1ull << e;
+                if (COUNT) n_exec += (lane == 0);
                 float g_px = 0.f, g_py = 0.f, g_sx = 0.f, g_sy = 0.f, g_rot = 0.f;
                 float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_op = 0.f;
                 if (((wm >> lane) & 1ull) && alive) { // main.cpp:595-605
@@ -275,39 +297,29 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                     alive = !(T < kMinThroughput);
                     if (COUNT) n_act++;
                 }
-                g_px = wave_sum_to_lane63(g_px);
-                g_py = wave_sum_to_lane63(g_py);
-                g_sx = wave_sum_to_lane63(g_sx);
-                g_sy = wave_sum_to_lane63(g_sy);
-                g_rot = wave_sum_to_lane63(g_rot);
-                g_r = wave_sum_to_lane63(g_r);
-                g_g = wave_sum_to_lane63(g_g);
-                g_b = wave_sum_to_lane63(g_b);
-                g_op = wave_sum_to_lane63(g_op);
+                wave_sum9_to_lane63(g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
                 if (lane == 63) { // order of the record: pos.xy, sx, sy, rot, color.rgb, opacity (main.cpp:85-93)
-                    float* acc = s_acc + e * 9;
-                    atomicAdd(acc + 0, g_px);
-                    atomicAdd(acc + 1, g_py);
-                    atomicAdd(acc + 2, g_sx);
-                    atomicAdd(acc + 3, g_sy);
-                    atomicAdd(acc + 4, g_rot);
-                    atomicAdd(acc + 5, g_r);
-                    atomicAdd(acc + 6, g_g);
-                    atomicAdd(acc + 7, g_b);
-                    atomicAdd(acc + 8, g_op);
+                    s_part[w][e][0] = make_float4(g_px, g_py, g_sx, g_sy);
+                    s_part[w][e][1] = make_float4(g_rot, g_r, g_g, g_b);
+                    s_part[w][e][2].x = g_op;
                 }
                 alive_mask = __ballot(alive);
             }
         }
+        if (lane == 0) s_touched[w] = touched;
         const int any = __syncthreads_or(alive ? 1 : 0);
         // one float-atomic burst per (tile, splat): 9 consecutive floats of grads[idx]
         for (int i = tid; i < cnt * 9; i += 256) {
-            const float v = s_acc[i];
-            if (v != 0.0f) {
-                const int e = i / 9;
-                atomicAdd(grads + (size_t)s_idx[par][e] * 9 + (i - e * 9), v);
-                s_acc[i] = 0.0f;
-            }
+            const int e = i / 9, k = i - e * 9;
+            float v = 0.0f;
+            bool any_w = false;
+#pragma unroll
+            for (int ww = 0; ww < 4; ww++)
+                if ((s_touched[ww] >> e) & 1ull) {
+                    v += reinterpret_cast<const float*>(&s_part[ww][e][0])[k];
+                    any_w = true;
+                }
+            if (any_w && v != 0.0f) atomicAdd(grads + (size_t)s_idx[par][e] * 9 + k, v);
         }
         if (!any) break;
     }
@@ -315,18 +327,26 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         atomicAdd(&counters->bwd_visited, n_vis);
         atomicAdd(&counters->bwd_active, n_act);
         if (tid == 0) atomicAdd(&counters->bwd_staged, n_staged);
+        if (lane == 0) atomicAdd(&counters->bwd_wave_execs, n_exec);
     }
 }
 
-__global__ __launch_bounds__(256) void sqerr_finalize_kernel(const double* __restrict__ tile_sqerr, int num_tiles,
-                                                             double* __restrict__ out)
+// One block, fixed summation order (deterministic MSE trace): 1024 threads, 8 loads in flight per thread.
+__global__ __launch_bounds__(1024) void sqerr_finalize_kernel(const double* __restrict__ tile_sqerr, int num_tiles,
+                                                              double* __restrict__ out)
 {
-    __shared__ double s[256];
-    double acc = 0.0;
-    for (int i = threadIdx.x; i < num_tiles; i += 256) acc += tile_sqerr[i];
-    s[threadIdx.x] = acc;
+    __shared__ double s[1024];
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int base = threadIdx.x; base < num_tiles; base += 8 * 1024) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int i = base + j * 1024;
+            if (i < num_tiles) a[j] += tile_sqerr[i];
+        }
+    }
+    s[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
     __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
+    for (int d = 512; d >= 1; d >>= 1) {
         if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d];
         __syncthreads();
     }
@@ -364,7 +384,7 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
 
 hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, hipStream_t stream)
 {
-    hipLaunchKernelGGL(sqerr_finalize_kernel, dim3(1), dim3(256), 0, stream, tile_sqerr, num_tiles, out);
+    hipLaunchKernelGGL(sqerr_finalize_kernel, dim3(1), dim3(1024), 0, stream, tile_sqerr, num_tiles, out);
     return hipGetLastError();
 }
 

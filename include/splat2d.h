@@ -94,6 +94,7 @@ typedef struct s2d_stats {
     uint64_t fwd_visited, fwd_active; /* S2D_CFG_COUNT_PAIRS: pairs inside the reference's x/y ranges, and those with T >= 1/256 */
     uint64_t bwd_visited, bwd_active;
     uint64_t fwd_staged, bwd_staged;  /* list entries the raster kernels actually staged (after tile retirement) */
+    uint64_t fwd_wave_execs, bwd_wave_execs; /* (wave, entry) pairs whose blend body ran (>= 1 live lane covered) */
     int32_t iterations;        /* == `iterations`, main.cpp:278 */
     int32_t first_nonfinite_iteration; /* -1 if none */
 } s2d_stats;
