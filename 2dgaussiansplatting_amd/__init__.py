@@ -68,7 +68,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or _build.LIB_PATH
+    path = path or os.environ.get("S2D_LIBRARY") or _build.LIB_PATH  # S2D_LIBRARY: A/B builds of the same ABI
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the trainer has no CPU fallback)" % path)

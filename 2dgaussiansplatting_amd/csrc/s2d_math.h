@@ -127,6 +127,21 @@ S2D_HD float exp_approx(float x)
     return x;
 }
 
+// exp_approx(-0.5f * d2), main.cpp:527 / :610, in one fused step: -0.5*d2 and the division by 8 are exact
+// scalings by powers of two, so 1 + (-0.5*d2)/8 has a single rounding -- the one fmaf(d2, -1/16, 1) performs.
+// (If the scaling underflows, both forms give exactly 1.)  Bit-identical to the two-step form; checked against
+// the oracle by tests/test_shared_math_host.py.
+S2D_HD float gauss_from_d2(float d2)
+{
+    float x = ::fmaf(d2, -0.0625f, 1.0f);
+    if (x < 0.00001814586175896693021059036255f)
+        return 0.0f;
+    x *= x;
+    x *= x;
+    x *= x;
+    return x;
+}
+
 // C float -> int conversion as the reference's x86-64 build performs it (cvttss2si): truncation
 // toward zero, and the "integer indefinite" value INT_MIN for NaN / out-of-range inputs.
 S2D_HD int cvt_trunc(float f)
@@ -240,7 +255,7 @@ S2D_HD float gauss_at(float px, float py, float pos_x, float pos_y, float a, flo
     float d2 = vx * mx + vy * my;
     *vx_out = vx;
     *vy_out = vy;
-    return exp_approx(-0.5f * d2);
+    return gauss_from_d2(d2);
 }
 
 // ----------------------------------------------------------------------------------------------

@@ -1,28 +1,38 @@
 // s2d_raster.hip -- tile-binned forward rasteriser and analytic backward pass.
 //
-// One 256-thread workgroup (4 wave64) per 16x16 image tile, one thread per pixel; wave w owns
-// rows 4w..4w+3 of the tile, so lane = 16*(row & 3) + column.  A tile walks its splat list
-// (ascending splat index == the reference's blend order, main.cpp:419/:552) in batches of 64
-// entries staged in LDS:
-//   * 4 threads per entry load the 64-byte projected record and evaluate the reference's exact
-//     per-row column range (solve_quadratic + int truncation, main.cpp:498-509) for 4 rows each,
-//     producing one 64-bit lane mask per (entry, wave): bit l set <=> the reference's loops visit
-//     that pixel for that splat.  The quadratic is solved once per (entry, row), not per pixel.
-//   * the blend loop then reads one wave-uniform mask per entry, skips the entry with a scalar
-//     branch when no live lane is covered, and otherwise evaluates main.cpp:523-533 per lane.
-// A pixel whose throughput fell below 1/256 never works again (main.cpp:520); when all 256 pixels
-// of the tile are in that state the workgroup stops walking its list (tile retirement).
+// One 256-thread workgroup (4 wave64) per 16x16 image tile, one thread per pixel.  Each wave owns a
+// WX x (64/WX) pixel block of the tile (kWaveW = 16: four 16x4 strips; kWaveW = 8: four 8x8 blocks), with
+// lane = WX * (row in block) + (column in block).  A tile walks its splat list (ascending splat index ==
+// the reference's blend order, main.cpp:419/:552) in batches of 64 entries staged in LDS:
+//   * 4 threads per entry load the 64-byte projected record and evaluate the reference's exact per-row
+//     column range (solve_quadratic + int truncation, main.cpp:498-509) for 4 tile rows each, producing one
+//     64-bit lane mask per (entry, wave): bit l set <=> the reference's loops visit that pixel for that
+//     splat.  The quadratic is solved once per (entry, row), not per pixel.
+//   * after the barrier lane l of every wave fetches the mask of entry l; a ballot of "mask != 0" is the
+//     set of entries that touch this wave at all, and the blend loop iterates over its set bits only
+//     (scalar bit tricks + v_readlane), skipping an entry with a scalar branch when no LIVE lane is covered.
+// A pixel whose throughput fell below 1/256 never works again (main.cpp:520); when all 256 pixels of the tile
+// are in that state the workgroup stops walking its list (tile retirement).
 //
-// Forward arithmetic is the reference's, operation for operation (-ffp-contract=off), so the
-// framebuffer is bit-identical to the oracle's.  The backward pass recomputes T and the running
-// colour the same way, then reduces each splat's nine partial gradients over the wave with DPP,
-// over the four waves through per-wave LDS slots (plain stores, fixed order), and issues one global
-// float-atomic burst per (tile, splat) into the N x 9 gradient array.
+// The alpha / throughput / colour arithmetic is the reference's, operation for operation
+// (-ffp-contract=off), in both kernels, so the framebuffer is bit-identical to the oracle's and the backward
+// pass makes exactly the forward's per-pixel decisions.  The backward pass then reduces each splat's nine
+// partial gradients over the wave with DPP, over the four waves through per-wave LDS slots (plain stores,
+// fixed order), and issues one global float-atomic burst per (tile, splat) into the N x 9 gradient array.
 #include "s2d_device.h"
 
 namespace s2d {
 
 constexpr int B = kRasterBatch;
+static_assert(B == 64, "lane l of a wave holds the mask of batch entry l");
+
+#ifndef S2D_WAVE_W
+#define S2D_WAVE_W 8
+#endif
+constexpr int kWaveW = S2D_WAVE_W;     // pixel columns per wave block: 16 (16x4 strips) or 8 (8x8 blocks)
+constexpr int kWaveH = 64 / kWaveW;    // pixel rows per wave block
+constexpr int kWavesX = kTile / kWaveW;
+static_assert(kWaveW == 16 || kWaveW == 8, "wave block is 16x4 or 8x8");
 
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so
 // that neighbouring tiles, which share most of their splat records, hit the same L2.  Speed only.
@@ -33,26 +43,48 @@ __device__ __forceinline__ int tile_of_block(int bid, int num_tiles)
     return t < num_tiles ? t : -1;
 }
 
-__device__ __forceinline__ unsigned long long wave_uniform_u64(unsigned long long v)
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src_lane)
 {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_lane);
+    const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_lane);
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// 64-bit lane mask of entry (q0, q1, begY, endY) for the wave that owns rows y_first..y_first+3.
-__device__ __forceinline__ unsigned long long wave_mask_of(const float4& q0, const float4& q1, int begY, int endY,
-                                                           int y_first, int x0, int W, int row_end)
+// Pixel of thread tid inside the tile.
+__device__ __forceinline__ void pixel_of_thread(int tid, int* lx, int* ly)
 {
-    unsigned long long m = 0;
+    const int w = tid >> 6, lane = tid & 63;
+    *lx = (w % kWavesX) * kWaveW + (lane % kWaveW);
+    *ly = (w / kWavesX) * kWaveH + (lane / kWaveW);
+}
+
+// Staging thread (se = entry, sub = 0..3) evaluates tile rows sub*4 .. sub*4+3 of entry se and deposits the
+// bits into the per-(wave, entry) lane masks, laid out s_mask[wave][entry] as 2 x 32-bit words each.
+__device__ __forceinline__ void stage_masks(uint32_t* s_mask32, int se, int sub, const float4& q0, const float4& q1,
+                                            int begY, int endY, int y_tile, int x_tile, int W, int row_end)
+{
+    uint32_t rm[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int yy = y_first + k;
-        uint32_t rm = 0;
-        if (yy < row_end) rm = row_mask16(q0.x, q0.y, q0.z, q0.w, q1.x, begY, endY, yy, x0, W);
-        m |= (unsigned long long)rm << (16 * k);
+        const int yy = y_tile + sub * 4 + k;
+        rm[k] = 0;
+        if (yy < row_end) rm[k] = row_mask16(q0.x, q0.y, q0.z, q0.w, q1.x, begY, endY, yy, x_tile, W);
     }
-    return m;
+    if (kWaveW == 16) {
+        // wave = sub; lane = 16 * k + column
+        s_mask32[(sub * B + se) * 2 + 0] = rm[0] | (rm[1] << 16);
+        s_mask32[(sub * B + se) * 2 + 1] = rm[2] | (rm[3] << 16);
+    } else {
+        // waves (wy, 0) and (wy, 1) with wy = sub >> 1; rows (sub & 1) * 4 + k of the 8x8 block; lane = 8 * row + column
+        const int wy = sub >> 1, half = sub & 1;
+#pragma unroll
+        for (int wx = 0; wx < 2; wx++) {
+            const int sh = 8 * wx;
+            const uint32_t word = ((rm[0] >> sh) & 0xFFu) | (((rm[1] >> sh) & 0xFFu) << 8) |
+                                  (((rm[2] >> sh) & 0xFFu) << 16) | (((rm[3] >> sh) & 0xFFu) << 24);
+            s_mask32[((wy * 2 + wx) * B + se) * 2 + half] = word;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -68,15 +100,17 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
     __shared__ float4 s_q0[B];
     __shared__ float4 s_q1[B];
     __shared__ float s_op[B];
-    __shared__ unsigned long long s_mask[B * 4];
+    __shared__ unsigned long long s_mask[4 * B]; // [wave][entry]
 
     const int tile = tile_of_block(blockIdx.x, g.num_tiles);
     if (tile < 0) return;
     const int tx = tile % g.tiles_x;
     const int ty = tile / g.tiles_x + g.trow0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int x = tx * kTile + (tid & 15);
-    const int y = ty * kTile + (tid >> 4);
+    int lx, ly;
+    pixel_of_thread(tid, &lx, &ly);
+    const int x = tx * kTile + lx;
+    const int y = ty * kTile + ly;
     const bool inside = x < g.W && y < g.row_end;
     const float px = (float)x + 0.5f, py = (float)y + 0.5f; // main.cpp:523
 
@@ -91,8 +125,8 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
         if (se < cnt) {
             const ProjRec* r = proj + list[base + se];
             const float4 q0 = r->q0, q1 = r->q1, q2 = r->q2;
-            s_mask[se * 4 + sub] = wave_mask_of(q0, q1, __float_as_int(q2.y), __float_as_int(q2.z),
-                                                ty * kTile + sub * 4, tx * kTile, g.W, g.row_end);
+            stage_masks(reinterpret_cast<uint32_t*>(s_mask), se, sub, q0, q1, __float_as_int(q2.y),
+                        __float_as_int(q2.z), ty * kTile, tx * kTile, g.W, g.row_end);
             if (sub == 0) {
                 s_q0[se] = q0;
                 s_q1[se] = q1;
@@ -103,8 +137,12 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
         unsigned long long alive_mask = __ballot(alive);
         if (alive_mask != 0ull || COUNT) {
-            for (int e = 0; e < cnt; e++) {
-                const unsigned long long wm = wave_uniform_u64(s_mask[e * 4 + w]);
+            const unsigned long long my_mask = (lane < cnt) ? s_mask[w * B + lane] : 0ull;
+            unsigned long long cand = __ballot(my_mask != 0ull); // entries that touch this wave's block at all
+            while (cand != 0ull) {
+                const int e = __builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                const unsigned long long wm = readlane_u64(my_mask, e);
                 if (COUNT) n_vis += (wm >> lane) & 1ull;
                 if ((wm & alive_mask) == 0ull) continue;
                 if (COUNT) n_exec += (lane == 0);
@@ -169,8 +207,30 @@ __device__ __forceinline__ void wave_sum9_to_lane63(float& a0, float& a1, float&
                  : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
 }
 
+// num / den, correctly rounded, from a once-refined reciprocal r ~ 1/den shared by several numerators: the
+// hardware's IEEE division sequence (v_rcp, one Newton step on the reciprocal, quotient, two residual
+// corrections with exact fma residuals) without its per-division scaling for denormal / huge operands, which
+// cannot occur here (den in [1e-15, 1], |num| <~ 1).  The quotient must be the one the reference computes:
+// c*T - S/(1-alpha) cancels down to a T_final-sized remainder, which magnifies a last-place difference in the
+// quotient by T/T_final (10^3..10^5 in flat image regions).
+__device__ __forceinline__ float div_by_recip(float num, float den, float r)
+{
+    float q = num * r;
+    q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
+    q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
+    return q;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // backward, main.cpp:548-712, + the squared error of main.cpp:796-805
+//
+// Per (pixel, splat) the reference adds nine terms (main.cpp:619, :654-655, :677-678, :685, :704).  They are
+// evaluated with the reference's own expressions: its three-term dot products (cc vx^2 + 2sc vx vy + ss vy^2,
+// ...) and the channel sum dL . dC/dalpha can cancel, and then carry rounding noise that only the same
+// operation order reproduces (the algebraically equal alpha*u^2/sx^3 with u = cos*vx + sin*vy is cheaper and
+// more accurate, but differs from the reference by up to 1e-4 of a splat's summed |terms| when its few live
+// pixels lie near u = 0).  Only factors that are plain products are regrouped or precomputed per entry
+// (1/sx^3, 1/sy^3, (sx^2-sy^2)/(sx^2 sy^2), 0.5*alpha*(2a vx + (b+c) vy) = alpha*mx): a few ulp per term.
 // ---------------------------------------------------------------------------------------------------
 template <bool COUNT>
 __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
@@ -184,10 +244,9 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
 {
     __shared__ float4 s_q0[B];
     __shared__ float4 s_q1[B];
-    __shared__ float4 s_e0[B]; // cc, 2sc, ss, 1/sx^3
-    __shared__ float4 s_e1[B]; // 1/sy^3, (sx^2-sy^2)/(sx^2 sy^2), cc-ss, sc
-    __shared__ float s_op[B];
-    __shared__ unsigned long long s_mask[B * 4];
+    __shared__ float4 s_e0[B]; // cc, 2sc, ss, sc
+    __shared__ float4 s_e1[B]; // 1/sx^3, 1/sy^3, (sx^2-sy^2)/(sx^2 sy^2), opacity
+    __shared__ unsigned long long s_mask[4 * B]; // [wave][entry]
     __shared__ uint32_t s_idx[2][B];
     // per-wave partial gradients of the batch: written once per (wave, entry) by lane 63 with plain stores,
     // summed over the 4 waves in a fixed order by the flush.  12 floats per slot keep float4 stores aligned.
@@ -200,8 +259,10 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     const int tx = tile % g.tiles_x;
     const int ty = tile / g.tiles_x + g.trow0;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int x = tx * kTile + (tid & 15);
-    const int y = ty * kTile + (tid >> 4);
+    int lx, ly;
+    pixel_of_thread(tid, &lx, &ly);
+    const int x = tx * kTile + lx;
+    const int y = ty * kTile + ly;
     const bool inside = x < g.W && y < g.row_end;
     const float px = (float)x + 0.5f, py = (float)y + 0.5f;
 
@@ -236,18 +297,16 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
             const uint32_t idx = list[base + se];
             const ProjRec* r = proj + idx;
             const float4 q0 = r->q0, q1 = r->q1, q2 = r->q2;
-            s_mask[se * 4 + sub] = wave_mask_of(q0, q1, __float_as_int(q2.y), __float_as_int(q2.z),
-                                                ty * kTile + sub * 4, tx * kTile, g.W, g.row_end);
+            stage_masks(reinterpret_cast<uint32_t*>(s_mask), se, sub, q0, q1, __float_as_int(q2.y),
+                        __float_as_int(q2.z), ty * kTile, tx * kTile, g.W, g.row_end);
             if (sub == 0) {
                 const float4 q3 = r->q3;
                 const float cosT = q2.w, sinT = q3.x, sx = q3.y, sy = q3.z;
-                const float cc = cosT * cosT, ss = sinT * sinT, sc = sinT * cosT;
                 const float sx2 = sx * sx, sy2 = sy * sy;
                 s_q0[se] = q0;
                 s_q1[se] = q1;
-                s_op[se] = q2.x;
-                s_e0[se] = make_float4(cc, 2.0f * sinT * cosT, ss, 1.0f / (sx2 * sx));
-                s_e1[se] = make_float4(1.0f / (sy2 * sy), (sx2 - sy2) / (sx2 * sy * sy), cc - ss, sc);
+                s_e0[se] = make_float4(cosT * cosT, 2.0f * sinT * cosT, sinT * sinT, sinT * cosT);
+                s_e1[se] = make_float4(1.0f / (sx2 * sx), 1.0f / (sy2 * sy), (sx2 - sy2) / (sx2 * sy * sy), q2.x);
                 s_idx[par][se] = idx;
             }
         }
@@ -256,8 +315,12 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         unsigned long long alive_mask = __ballot(alive);
         unsigned long long touched = 0ull;
         if (alive_mask != 0ull || COUNT) {
-            for (int e = 0; e < cnt; e++) {
-                const unsigned long long wm = wave_uniform_u64(s_mask[e * 4 + w]);
+            const unsigned long long my_mask = (lane < cnt) ? s_mask[w * B + lane] : 0ull;
+            unsigned long long cand = __ballot(my_mask != 0ull);
+            while (cand != 0ull) {
+                const int e = __builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                const unsigned long long wm = readlane_u64(my_mask, e);
                 if (COUNT) n_vis += (wm >> lane) & 1ull;
                 if ((wm & alive_mask) == 0ull) continue;
                 touched |= 1ull << e;
@@ -267,33 +330,39 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                 if (((wm >> lane) & 1ull) && alive) { // main.cpp:595-605
                     const float4 q0 = s_q0[e], q1 = s_q1[e];
                     const float4 e0 = s_e0[e], e1 = s_e1[e];
-                    const float a = q0.z, b = q0.w, d = q1.x;
-                    float vx, vy;
-                    const float G = gauss_at(px, py, q0.x, q0.y, a, b, d, &vx, &vy); // main.cpp:607-610
-                    const float alpha = G * s_op[e];                                   // main.cpp:611
-                    const float dC_dc = alpha * T;                                     // main.cpp:618
+                    // ---- the reference's operations, in its order (decides T, alive, the running colour) ----
+                    const float vx = px - q0.x, vy = py - q0.y;                      // main.cpp:607-608
+                    const float mx = q0.z * vx + q0.w * vy;                          // inv_cov * v
+                    const float my = q0.w * vx + q1.x * vy;
+                    const float G = gauss_from_d2(vx * mx + vy * my);                // main.cpp:609-610
+                    const float alpha = G * e1.w;                                    // main.cpp:611
+                    const float Tr = T * q1.y, Tg = T * q1.z, Tb = T * q1.w;
+                    cr += Tr * alpha;                                                // main.cpp:623-625
+                    cg += Tg * alpha;
+                    cb += Tb * alpha;
+                    // ---- gradient terms ----
+                    const float dC_dc = alpha * T;                                   // main.cpp:618
                     g_r = dLr * dC_dc;
                     g_g = dLg * dC_dc;
                     g_b = dLb * dC_dc;
-                    cr += T * q1.y * alpha;                                            // main.cpp:623-625
-                    cg += T * q1.z * alpha;
-                    cb += T * q1.w * alpha;
-                    // c*T - S/(1-alpha) cancels to a small remainder (T_final-sized) out of T-sized terms, so
-                    // the quotient is taken exactly as the reference takes it (IEEE division), main.cpp:627-628
+                    // S / (1 - alpha + 1e-15), main.cpp:627-628: three quotients over one denominator
                     const float den = 1.0f - alpha + 1.0e-15f;
-                    const float dCa_r = q1.y * T - (fin.x - cr) / den;                // S = final - colour
-                    const float dCa_g = q1.z * T - (fin.y - cg) / den;
-                    const float dCa_b = q1.w * T - (fin.z - cb) / den;
-                    const float gs = (dLr * dCa_r + dLg * dCa_g) + dLb * dCa_b;       // dL_dalpha_rgb, :629-630
-                    const float bc = b + b;                                            // b + c, :639-640
-                    g_px = gs * (0.5f * alpha * (2.0f * a * vx + bc * vy));
-                    g_py = gs * (0.5f * alpha * (2.0f * d * vy + bc * vx));
+                    float rd = __builtin_amdgcn_rcpf(den);
+                    rd = __builtin_fmaf(__builtin_fmaf(-den, rd, 1.0f), rd, rd);
+                    const float dCa_r = Tr - div_by_recip(fin.x - cr, den, rd);      // S = final - colour
+                    const float dCa_g = Tg - div_by_recip(fin.y - cg, den, rd);
+                    const float dCa_b = Tb - div_by_recip(fin.z - cb, den, rd);
+                    // the three channel products may cancel: same products, same order as main.cpp:629-630
+                    const float gs = (dLr * dCa_r + dLg * dCa_g) + dLb * dCa_b;
+                    const float ga = gs * alpha;
+                    g_px = ga * mx;                                                  // main.cpp:639, :654
+                    g_py = ga * my;                                                  // main.cpp:640, :655
                     const float vxx = vx * vx, vxy = vx * vy, vyy = vy * vy;
-                    g_sx = gs * (alpha * e0.w * ((e0.x * vxx + e0.y * vxy) + e0.z * vyy)); // :657-659
-                    g_sy = gs * (alpha * e1.x * ((e0.z * vxx - e0.y * vxy) + e0.x * vyy)); // :660-662
-                    g_rot = gs * (alpha * e1.y * (e1.z * vx * vy - e1.w * (vxx - vyy)));   // :680-685
-                    g_op = gs * G;                                                     // main.cpp:703-704
-                    T *= (1.0f - alpha);                                               // main.cpp:707
+                    g_sx = (ga * e1.x) * ((e0.x * vxx + e0.y * vxy) + e0.z * vyy);   // main.cpp:657-659, :677
+                    g_sy = (ga * e1.y) * ((e0.z * vxx - e0.y * vxy) + e0.x * vyy);   // main.cpp:660-662, :678
+                    g_rot = (ga * e1.z) * ((e0.x - e0.z) * vx * vy - e0.w * (vxx - vyy)); // main.cpp:680-685
+                    g_op = gs * G;                                                   // main.cpp:703-704
+                    T *= (1.0f - alpha);                                             // main.cpp:707
                     alive = !(T < kMinThroughput);
                     if (COUNT) n_act++;
                 }
