@@ -1,0 +1,182 @@
+// splat2d_train.cpp -- headless C++ host loop on top of the C ABI (include/splat2d.h).
+//
+// Mirrors the shape of the reference's main() (/root/reference/main.cpp:236-856) without its window:
+//   load imageRef (main.cpp:253-259)  ->  NSplat splats (:271-272)  ->  init() (:280-307)  ->
+//   loop { forward (:414-546); backward (:548-712); Adam + constraints (:714-785); MSE (:796-805);
+//          printf("%d itr, mse %.4f\n") (:807); iterations++ (:809) }
+// The three passes run on the MI355X through s2d_step(); this file owns only what main() owns besides them:
+// the image, the flags the GUI exposed ("Optimize opacity" :825, "Restart" :828-831) and the trace line.
+// It is plain C++ (g++), links the library, and has no compute of its own.
+//
+//   splat2d_train --image tests/golden/squirrel_cls_mini_268x213.s2di --splats 1024 --iters 300
+//   splat2d_train --synthetic 4096x4096 --splats 1000000 --iters 100 --quiet
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "splat2d.h"
+
+namespace {
+
+struct Options {
+    std::string image;          // .s2di fixture (raw RGB8, see tools/make_image_fixtures.py)
+    int syn_w = 0, syn_h = 0;   // --synthetic WxH
+    int n_splats = 1024;        // NSplat, main.cpp:271
+    int iters = 300;
+    int batch = 1;              // iterations queued per s2d_step call (1 = print after every iteration, like the reference)
+    bool optimize_opacity = false;
+    int opacity_from = 0;       // iteration from which the flag is on (the GUI checkbox can be ticked mid-run)
+    int restart_at = -1;        // press "Restart" before this iteration (main.cpp:828-831)
+    bool quiet = false;
+    std::string out_ppm;
+    int device = 0;
+    int rebin_interval = 0;
+};
+
+bool load_s2di(const std::string& path, int* w, int* h, std::vector<uint8_t>* rgb)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[4];
+    uint32_t hdr[3];
+    bool ok = std::fread(magic, 1, 4, f) == 4 && std::memcmp(magic, "S2DI", 4) == 0 && std::fread(hdr, 4, 3, f) == 3 &&
+              hdr[2] == 3;
+    if (ok) {
+        *w = (int)hdr[0];
+        *h = (int)hdr[1];
+        rgb->resize((size_t)hdr[0] * hdr[1] * 3);
+        ok = std::fread(rgb->data(), 1, rgb->size(), f) == rgb->size();
+    }
+    std::fclose(f);
+    return ok;
+}
+
+bool write_ppm(const std::string& path, int w, int h, const std::vector<float>& rgba)
+{
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fprintf(f, "P6\n%d %d\n255\n", w, h);
+    std::vector<uint8_t> row((size_t)w * 3);
+    for (int y = 0; y < h; y++) {
+        for (int x = 0; x < w; x++)
+            for (int c = 0; c < 3; c++) {
+                float v = rgba[((size_t)y * w + x) * 4 + c] * 255.0f + 0.5f;
+                row[(size_t)x * 3 + c] = (uint8_t)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));
+            }
+        std::fwrite(row.data(), 1, row.size(), f);
+    }
+    std::fclose(f);
+    return true;
+}
+
+int usage()
+{
+    std::fprintf(stderr,
+                 "usage: splat2d_train (--image file.s2di | --synthetic WxH) [--splats N] [--iters K] [--batch B]\n"
+                 "                     [--optimize-opacity [--opacity-from IT]] [--restart-at IT] [--out-ppm file]\n"
+                 "                     [--device D] [--rebin-interval R] [--quiet]\n");
+    return 2;
+}
+
+#define CK(call)                                                                        \
+    do {                                                                                \
+        int rc_ = (call);                                                               \
+        if (rc_ != S2D_OK) {                                                            \
+            std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, s2d_last_error(ctx));    \
+            if (ctx) s2d_destroy(ctx);                                                  \
+            return rc_ == S2D_E_NONFINITE ? 3 : 1; /* the reference abort()s, main.cpp:752-785 */ \
+        }                                                                               \
+    } while (0)
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    Options o;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        auto next = [&](const char* what) -> const char* {
+            if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", what); std::exit(2); }
+            return argv[++i];
+        };
+        if (a == "--image") o.image = next("--image");
+        else if (a == "--synthetic") { if (std::sscanf(next("--synthetic"), "%dx%d", &o.syn_w, &o.syn_h) != 2) return usage(); }
+        else if (a == "--splats") o.n_splats = std::atoi(next("--splats"));
+        else if (a == "--iters") o.iters = std::atoi(next("--iters"));
+        else if (a == "--batch") o.batch = std::atoi(next("--batch"));
+        else if (a == "--optimize-opacity") o.optimize_opacity = true;
+        else if (a == "--opacity-from") o.opacity_from = std::atoi(next("--opacity-from"));
+        else if (a == "--restart-at") o.restart_at = std::atoi(next("--restart-at"));
+        else if (a == "--out-ppm") o.out_ppm = next("--out-ppm");
+        else if (a == "--device") o.device = std::atoi(next("--device"));
+        else if (a == "--rebin-interval") o.rebin_interval = std::atoi(next("--rebin-interval"));
+        else if (a == "--quiet") o.quiet = true;
+        else return usage();
+    }
+    if (o.image.empty() == (o.syn_w == 0) || o.n_splats < 0 || o.iters < 0 || o.batch < 1) return usage();
+
+    // imageRef, main.cpp:253-259
+    int W = o.syn_w, H = o.syn_h;
+    std::vector<float> imageRef;
+    if (!o.image.empty()) {
+        std::vector<uint8_t> rgb;
+        if (!load_s2di(o.image, &W, &H, &rgb)) {
+            std::fprintf(stderr, "cannot read %s\n", o.image.c_str());
+            return 1;
+        }
+        imageRef.resize((size_t)W * H * 4);
+        for (size_t p = 0; p < (size_t)W * H; p++) { // Image2DRGBA8_to_Image2DRGBA32: byte / 255.0f
+            for (int c = 0; c < 3; c++) imageRef[p * 4 + c] = (float)rgb[p * 3 + c] / 255.0f;
+            imageRef[p * 4 + 3] = 1.0f;
+        }
+    }
+
+    s2d_ctx* ctx = nullptr;
+    s2d_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = sizeof(cfg);
+    cfg.width = W;
+    cfg.height = H;
+    cfg.n_splats = o.n_splats; // int NSplat = 1024; main.cpp:271
+    cfg.device = o.device;
+    cfg.rebin_interval = o.rebin_interval;
+    CK(s2d_create(&cfg, &ctx));
+    if (!o.image.empty()) CK(s2d_set_target(ctx, imageRef.data()));
+    else CK(s2d_set_target_synthetic(ctx));
+    CK(s2d_init_splats(ctx)); // init(); main.cpp:307
+
+    int iterations = 0; // main.cpp:278
+    std::vector<double> mse((size_t)o.batch);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (iterations < o.iters) { // while (pr::NextFrame() == false), main.cpp:334
+        if (iterations == o.restart_at) { // ImGui::Button("Restart"), main.cpp:828-831
+            CK(s2d_init_splats(ctx));
+            o.restart_at = -1;
+        }
+        int k = o.batch;
+        if (k > o.iters - iterations) k = o.iters - iterations;
+        if (o.optimize_opacity && iterations < o.opacity_from && iterations + k > o.opacity_from) k = o.opacity_from - iterations;
+        if (o.restart_at > iterations && iterations + k > o.restart_at) k = o.restart_at - iterations;
+        const bool opacity_now = o.optimize_opacity && iterations >= o.opacity_from; // bool optimizeOpacity, main.cpp:317
+        CK(s2d_step(ctx, k, opacity_now ? S2D_STEP_OPTIMIZE_OPACITY : 0u, mse.data()));
+        if (!o.quiet)
+            for (int j = 0; j < k; j++) std::printf("%d itr, mse %.4f\n", iterations + j, mse[(size_t)j]); // main.cpp:807
+        iterations += k; // main.cpp:809
+    }
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats)\n", iterations, secs,
+                 secs > 0 ? iterations / secs : 0.0, W, H, o.n_splats);
+
+    if (!o.out_ppm.empty()) {
+        std::vector<float> image0((size_t)W * H * 4);
+        CK(s2d_forward(ctx));
+        CK(s2d_get_image(ctx, image0.data())); // tex0->upload(image0), main.cpp:794
+        if (!write_ppm(o.out_ppm, W, H, image0)) std::fprintf(stderr, "cannot write %s\n", o.out_ppm.c_str());
+    }
+    s2d_destroy(ctx);
+    return 0;
+}

@@ -25,13 +25,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def slab_rows(H, rank, world):
-    tile_rows = (H + 15) // 16
-    t0 = tile_rows * rank // world
-    t1 = tile_rows * (rank + 1) // world
-    return t0 * 16, min(t1 * 16, H)
-
-
 def host_cores():
     """CPU cores this process may really use: affinity mask, capped by the cgroup CPU quota."""
     n = os.cpu_count() or 1
@@ -80,6 +73,7 @@ def main():
     import numpy as np
     import torch
     S2D = importlib.import_module("2dgaussiansplatting_amd")
+    D = importlib.import_module("2dgaussiansplatting_amd.distributed")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -99,7 +93,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     W, H, n = args.width, args.height, args.splats
-    r0, r1 = slab_rows(H, rank, world)
+    r0, r1 = D.slab_rows(H, rank, world)
     # a real (non-default) stream: its handle goes into the C ABI, so the library's kernels, the RCCL
     # all-reduce and the timing events below are all ordered on the same HIP stream
     stream = torch.cuda.Stream()
@@ -112,16 +106,13 @@ def main():
     t.set_target_synthetic()
     t.init()
 
+    step = D.SlabStep(t, grads, dist)  # forward, backward, all-reduce(grads), Adam
+
     def one_step(ev=None):
-        t.forward()
-        if ev is not None:
-            ev[0].record(stream)
-        t.backward()
-        if ev is not None:
-            ev[1].record(stream)
-        if dist is not None:
-            dist.all_reduce(grads)  # sum of the per-slab partial gradients, fp32, in place
-        t.adam_step()
+        if ev is None:
+            step()
+        else:  # HIP events around the backward raster kernel, on the stream it is launched on
+            step(after_forward=lambda: ev[0].record(stream), after_backward=lambda: ev[1].record(stream))
 
     for _ in range(args.warmup):
         one_step()
@@ -144,7 +135,7 @@ def main():
     bwd_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)], dtype=torch.float64, device="cuda")
     if dist is not None:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(sq)
+        D.reduce_sqerr(sq, dist)
         dist.all_reduce(bwd_ms, op=dist.ReduceOp.MAX)
     dt = float(dt_t.item())
     mse_last = float(sq[-1].item()) / (H * W * 3) if args.steps else float("nan")
@@ -152,10 +143,10 @@ def main():
 
     if rank == 0:
         its = args.steps / dt
-        # dominant kernel: raster_backward.  Algorithmic bytes per launch: per pixel of the
-        # slab it reads the framebuffer (16 B) and the target (16 B); per splat it reads the projected record
-        # once (64 B) and writes the 9 gradient floats once (36 B).
-        bwd_bytes = 32.0 * W * (r1 - r0) + (64.0 + 36.0) * n
+        # dominant kernel: raster_backward.  Algorithmic bytes per launch: per
+        # pixel of the slab it reads the framebuffer (16 B) and the target (16 B); per splat it reads the
+        # parameters once (36 B) and writes the 9 gradient floats once (36 B).
+        bwd_bytes = 32.0 * W * (r1 - r0) + 72.0 * n
         bwd_s = float(bwd_ms.item()) * 1e-3
         achieved = bwd_bytes / bwd_s / 1e9 if bwd_s > 0 else 0.0
         traffic = None

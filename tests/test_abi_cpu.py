@@ -1,0 +1,114 @@
+"""CPU tests of the boundary: the C-ABI library builds for gfx950, loads, exports every symbol the header
+declares, agrees with the ctypes binding on struct layouts, and fails loudly (no fallback) without a GPU."""
+import ctypes as C
+import importlib
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+S2D = importlib.import_module("2dgaussiansplatting_amd")
+HEADER = os.path.join(O.ROOT, "include", "splat2d.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    S2D._build.build_hip_library()
+    return S2D.load_library()
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(s2d_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), n
+    assert sorted(S2D.ABI_SYMBOLS) == names  # the binding's own list is the header's list
+    assert lib.s2d_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    code = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    #include "splat2d.h"
+    int main(void) {
+        printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(s2d_splat), sizeof(s2d_splat_adam), sizeof(s2d_config),
+               sizeof(s2d_stats), offsetof(s2d_config, stream), offsetof(s2d_config, training_rate),
+               offsetof(s2d_stats, iterations), offsetof(s2d_stats, fwd_wave_execs));
+        return 0;
+    }'''
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write(code)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(O.ROOT, "include"), src, "-o", exe])
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    assert got[0] == 36 == S2D.SPLAT_DTYPE.itemsize      # struct Splat, main.cpp:85-93
+    assert got[1] == 72 == S2D.ADAM_DTYPE.itemsize       # struct SplatAdam, main.cpp:158-166
+    assert got[2] == C.sizeof(S2D._Config)
+    assert got[3] == C.sizeof(S2D._Stats)
+    assert got[4] == S2D._Config.stream.offset and got[5] == S2D._Config.training_rate.offset
+    assert got[6] == S2D._Stats.iterations.offset and got[7] == S2D._Stats.fwd_wave_execs.offset
+    assert O.SPLAT_DTYPE == S2D.SPLAT_DTYPE and O.ADAM_DTYPE.itemsize == S2D.ADAM_DTYPE.itemsize
+
+
+def test_create_rejects_bad_configs(lib):
+    h = C.c_void_p()
+    cfg = S2D._Config()
+    assert lib.s2d_create(C.byref(cfg), C.byref(h)) == 1      # struct_size missing
+    cfg.struct_size = C.sizeof(S2D._Config)
+    cfg.width, cfg.height, cfg.n_splats = 0, 10, 1
+    assert lib.s2d_create(C.byref(cfg), C.byref(h)) == 1
+    cfg.width, cfg.height = 64, 64
+    cfg.row_begin, cfg.row_end = 8, 64                          # slab must start on a tile row
+    assert lib.s2d_create(C.byref(cfg), C.byref(h)) == 1
+    cfg.row_begin, cfg.row_end = 32, 16
+    assert lib.s2d_create(C.byref(cfg), C.byref(h)) == 1
+    assert lib.s2d_create(None, C.byref(h)) == 1
+    assert lib.s2d_forward(None) == 1 and lib.s2d_step(None, 1, 0, None) == 1
+
+
+def _gpu_present():
+    return os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK)
+
+
+@pytest.mark.skipif(_gpu_present(), reason="a GPU is present: the no-device error cannot be provoked")
+def test_no_device_is_a_loud_error_not_a_fallback(lib):
+    with pytest.raises(S2D.S2DError) as ei:
+        S2D.Trainer(64, 64, 10)
+    assert ei.value.code == 2 and "no CPU fallback" in str(ei.value)
+    train = S2D._build.build_host_program()
+    r = subprocess.run([train, "--synthetic", "32x32", "--splats", "4", "--iters", "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    """The oracle is test infrastructure: nothing under the package or include/ may include, link or load it."""
+    pkg = os.path.join(O.ROOT, "2dgaussiansplatting_amd")
+    for base in (pkg, os.path.join(O.ROOT, "include")):
+        for dp, _, files in os.walk(base):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    assert "s2d_oracle" not in txt and "s2do_" not in txt and "oracle_lib" not in txt, os.path.join(dp, f)
+    out = subprocess.check_output(["ldd", S2D._build.LIB_PATH], text=True)
+    assert "oracle" not in out and "hostcheck" not in out
+
+
+def test_hip_sources_have_no_cuda_or_dual_path():
+    csrc = os.path.join(O.ROOT, "2dgaussiansplatting_amd", "csrc")
+    for f in os.listdir(csrc):
+        txt = open(os.path.join(csrc, f)).read()
+        for bad in ("__HIP_PLATFORM_AMD__", "cuda_runtime", "__CUDACC__", "hipify", "triton"):
+            assert bad not in txt, (f, bad)

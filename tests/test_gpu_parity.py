@@ -373,3 +373,57 @@ def test_cached_tile_lists_stay_exact(lr, interval):
         assert st["rebins"] < 24 // 2   # lists really were re-used
     else:
         assert st["rebins"] > 24 // interval  # unscheduled rebuilds happened
+
+
+# ---------------------------------------------------------------------------------------------
+# row slabs (the multi-GPU partition) and the C++ host loop
+# ---------------------------------------------------------------------------------------------
+def test_row_slab_contexts_add_up_to_the_full_image():
+    """Two slab contexts on one GPU: framebuffers tile the image bit-exactly, partial gradients and squared
+    errors add up to the single-context result (what the RCCL all-reduce sums across GPUs)."""
+    D = importlib.import_module("2dgaussiansplatting_amd.distributed")
+    tgt = mini_target()
+    o, full = make_pair(tgt, 2000, 3)
+    full.forward(); full.backward()
+    img_full, g_full, mse_full = full.get_image(), full.get_grads().view(np.float32).reshape(-1, 9), full.mse()
+    full.close()
+    o.forward()
+    _, dsum, dabs = o.backward_stats()
+    img = np.zeros_like(img_full)
+    g = np.zeros((2000, 9), dtype=np.float64)
+    mse = 0.0
+    for rank in range(2):
+        r0, r1 = D.slab_rows(o.H, rank, 2)
+        with S2D.Trainer(o.W, o.H, 2000, row_begin=r0, row_end=r1) as t:
+            t.set_target(tgt)
+            t.set_splats(o.splats.view(S2D.SPLAT_DTYPE))
+            t.forward(); t.backward()
+            part = t.get_image()
+            assert not part[:r0].any() and not part[r1:].any()
+            img[r0:r1] = part[r0:r1]
+            g += t.get_grads().view(np.float32).reshape(-1, 9)
+            mse += t.mse()
+    assert img.tobytes() == img_full.tobytes()
+    assert abs(mse - mse_full) <= 1e-12 * mse_full
+    nz = dabs > 0
+    assert (np.abs(g - dsum)[nz] / dabs[nz]).max() <= 1e-6
+    assert (np.abs(g - g_full)[nz] / dabs[nz]).max() <= 1e-6
+
+
+def test_cpp_host_loop_prints_the_reference_trace():
+    """2dgaussiansplatting_amd/host/splat2d_train.cpp: the headless main() loop, as-shipped configuration."""
+    import subprocess
+    exe = S2D._build.build_host_program()
+    r = subprocess.run([exe, "--image", MINI, "--splats", "1024", "--iters", "12"], capture_output=True, text=True, check=True)
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "0 itr, mse 5934.9042"       # main.cpp:807, SURVEY Appendix C
+    want = [5934.9042, 4659.3289, 3634.5384, 2840.9659, 2253.0626, 1839.7870, 1567.4046, 1401.9065,
+            1311.3069, 1267.7320, 1248.9938, 1244.4892]
+    got = [float(l.split("mse")[1]) for l in lines]
+    assert [int(l.split()[0]) for l in lines] == list(range(12))
+    np.testing.assert_allclose(got, want, rtol=2e-5)
+    # opacity checkbox ticked after the first frame (the survey's second known-answer trace), batched steps
+    r = subprocess.run([exe, "--image", MINI, "--splats", "1024", "--iters", "11", "--batch", "4",
+                        "--optimize-opacity", "--opacity-from", "1"], capture_output=True, text=True, check=True)
+    got = [float(l.split("mse")[1]) for l in r.stdout.strip().splitlines()]
+    assert abs(got[10] - 1145.5531) / 1145.5531 < 1e-4
