@@ -25,6 +25,7 @@ ADAM_DTYPE = np.dtype([("mv", "<f4", (9, 2))])
 
 S2D_STEP_OPTIMIZE_OPACITY = 0x1
 S2D_CFG_COUNT_PAIRS = 0x1
+S2D_BWD_SKIP_OPACITY_GRAD = 0x1
 STATUS_NAMES = {0: "S2D_OK", 1: "S2D_E_INVALID", 2: "S2D_E_HIP", 3: "S2D_E_NONFINITE", 4: "S2D_E_NOMEM",
                 5: "S2D_E_STATE"}
 
@@ -87,7 +88,7 @@ def load_library(path=None):
     L.s2d_get_adam.argtypes = [vp, vp, vp, vp, vp]
     L.s2d_forward.argtypes = [vp]
     L.s2d_get_image.argtypes = [vp, vp]
-    L.s2d_backward.argtypes = [vp]
+    L.s2d_backward.argtypes = [vp, u32]
     L.s2d_get_grads.argtypes = [vp, vp]
     L.s2d_adam_step.argtypes = [vp, u32]
     L.s2d_step.argtypes = [vp, i32, u32, vp]
@@ -142,6 +143,7 @@ class Trainer:
             self._h = None
             raise S2DError(rc, msg)
         self.optimize_opacity = False  # main.cpp:317
+        self.lean_backward = False     # backward() may skip the opacity gradient while optimize_opacity is off
 
     # -- lifetime
     def close(self):
@@ -211,8 +213,12 @@ class Trainer:
         self._ck(self.L.s2d_get_image(self._h, _p(a)))
         return a
 
-    def backward(self):
-        self._ck(self.L.s2d_backward(self._h))
+    def backward(self, skip_opacity_grad=None):
+        """Backward pass.  skip_opacity_grad=None: skip dSplats.opacity exactly when optimize_opacity is off and
+        `lean_backward` was requested (bench / training loops); False: always compute it, as the reference does."""
+        if skip_opacity_grad is None:
+            skip_opacity_grad = self.lean_backward and not self.optimize_opacity
+        self._ck(self.L.s2d_backward(self._h, S2D_BWD_SKIP_OPACITY_GRAD if skip_opacity_grad else 0))
 
     def get_grads(self):
         a = np.zeros(self.n, dtype=SPLAT_DTYPE)

@@ -191,12 +191,12 @@ int queue_forward(s2d_ctx* c)
     return S2D_OK;
 }
 
-int queue_backward(s2d_ctx* c)
+int queue_backward(s2d_ctx* c, bool need_opacity_grad)
 {
     if (!c->have_forward) return fail(c, S2D_E_STATE, "s2d_backward needs s2d_forward on the current parameters");
     const int slot = c->iterations % c->trace_cap;
     S2D_HIP(c, launch_raster_backward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->d_grads,
-                                      c->d_tile_sqerr, c->g,
+                                      c->d_tile_sqerr, c->g, need_opacity_grad,
                                       (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
     S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->stream));
     c->last_sqerr_slot = slot;
@@ -433,11 +433,11 @@ int s2d_get_image(s2d_ctx* c, float* rgba32f)
     return S2D_OK;
 }
 
-int s2d_backward(s2d_ctx* c)
+int s2d_backward(s2d_ctx* c, uint32_t flags)
 {
     if (!c) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
-    return queue_backward(c);
+    return queue_backward(c, !(flags & S2D_BWD_SKIP_OPACITY_GRAD));
 }
 
 int s2d_get_grads(s2d_ctx* c, s2d_splat* dsplats)
@@ -468,7 +468,7 @@ int s2d_step(s2d_ctx* c, int32_t iters, uint32_t flags, double* mse_out)
         const int first_iter = c->iterations;
         for (int k = 0; k < chunk; k++) {
             if (int rc = queue_forward(c)) return rc;
-            if (int rc = queue_backward(c)) return rc;
+            if (int rc = queue_backward(c, (flags & S2D_STEP_OPTIMIZE_OPACITY) != 0)) return rc;
             if (int rc = queue_adam(c, flags)) return rc;
         }
         if (mse_out) {

@@ -84,7 +84,8 @@ hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list,
                                  float4* image0, Geometry g, PairCounters* counters, hipStream_t stream);
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
                                   const float4* image0, const float4* image_ref, float* grads,
-                                  double* tile_sqerr, Geometry g, PairCounters* counters, hipStream_t stream);
+                                  double* tile_sqerr, Geometry g, bool need_opacity_grad, PairCounters* counters,
+                                  hipStream_t stream);
 // Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
 hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, hipStream_t stream);
 

@@ -173,38 +173,80 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Wave-wide sums of nine values by DPP: afterwards lane 63 holds the nine totals.
-// Six steps per value: xor-1 and xor-2 inside each quad, half-mirror and mirror inside each row of 16
-// lanes (every lane of a row then holds the row's sum), row_bcast15 into rows 1 and 3, row_bcast31 into
-// rows 2 and 3.  Written as ONE asm block in step-major order: hipcc packs the source-level adds into
-// v_pk_add_f32, which cannot carry a DPP modifier (3 instructions per step instead of 1), and in this order
-// every register is read again only nine instructions after it was written, so the DPP read-after-VALU-write
-// wait states are covered without padding (the leading s_nop covers the producers of the inputs).
-// All 64 lanes are active here (wave-uniform control flow).
+// Wave-wide sums of the nine partial gradients.
+//
+// Eight of them go through a PACKED butterfly: at every level two registers are folded into one, so the
+// number of live registers halves together with the number of lanes per value:
+//   level 32: v_permlane32_swap(x, y) makes x = [x.lo | y.lo], y = [x.hi | y.hi]; x + y holds the half-folded x
+//             in lanes 0-31 and the half-folded y in lanes 32-63           (8 -> 4 registers: 4 swaps + 4 adds)
+//   level 16: v_permlane16_swap the same way on rows of 16 lanes           (4 -> 2 registers: 2 swaps + 2 adds)
+//   level  8: two bank-masked DPP adds (row_ror:8) write the folded first register into lanes 0-7 and the
+//             folded second register into lanes 8-15 of every row          (2 -> 1 register: 2 adds)
+//   levels 4, 2, 1: row_half_mirror, quad_perm xor 1, quad_perm xor 2      (3 adds)
+// 17 VALU instructions instead of 48; afterwards every lane of the 8-lane group g = lane >> 3 holds the total
+// of value bitrev3(g).  The ninth value (the opacity gradient) takes the plain six-step DPP chain to lane 63,
+// interleaved with the tail of the butterfly so that the DPP read-after-write wait states are mostly filled;
+// it is skipped when the caller does not need it.  All 64 lanes are active here (wave-uniform control flow).
 // ---------------------------------------------------------------------------------------------------
-#define S2D_DPP9(ctrl)                                  \
-    "v_add_f32_dpp %0, %0, %0 " ctrl "\n"               \
-    "v_add_f32_dpp %1, %1, %1 " ctrl "\n"               \
-    "v_add_f32_dpp %2, %2, %2 " ctrl "\n"               \
-    "v_add_f32_dpp %3, %3, %3 " ctrl "\n"               \
-    "v_add_f32_dpp %4, %4, %4 " ctrl "\n"               \
-    "v_add_f32_dpp %5, %5, %5 " ctrl "\n"               \
-    "v_add_f32_dpp %6, %6, %6 " ctrl "\n"               \
-    "v_add_f32_dpp %7, %7, %7 " ctrl "\n"               \
-    "v_add_f32_dpp %8, %8, %8 " ctrl "\n"
-
-__device__ __forceinline__ void wave_sum9_to_lane63(float& a0, float& a1, float& a2, float& a3, float& a4, float& a5,
-                                                    float& a6, float& a7, float& a8)
+__device__ __forceinline__ void swap_fold32(float& x, float& y)
 {
-    asm volatile("s_nop 1\n"
-                 S2D_DPP9("quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
-                 S2D_DPP9("quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")
-                 S2D_DPP9("row_half_mirror row_mask:0xf bank_mask:0xf")
-                 S2D_DPP9("row_mirror row_mask:0xf bank_mask:0xf")
-                 S2D_DPP9("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 S2D_DPP9("row_bcast:31 row_mask:0xc bank_mask:0xf")
-                 "s_nop 1\n"
-                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8));
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ void swap_fold16(float& x, float& y)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+template <bool NINTH>
+__device__ __forceinline__ float wave_sum8_packed(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
+                                                  float a7, float& a8)
+{
+    swap_fold32(a0, a1); // a0 = [a0 | a1]
+    swap_fold32(a2, a3);
+    swap_fold32(a4, a5);
+    swap_fold32(a6, a7);
+    swap_fold16(a0, a2); // rows: a0, a2, a1, a3
+    swap_fold16(a4, a6); // rows: a4, a6, a5, a7
+    float d;
+    if (NINTH) {
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+                     "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+                     "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 0\n"
+                     "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                     "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 0\n"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                     "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 0\n"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                     "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     : "=&v"(d), "+v"(a8)
+                     : "v"(a0), "v"(a4));
+    } else {
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n"
+                     "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     : "=&v"(d)
+                     : "v"(a0), "v"(a4));
+    }
+    return d;
 }
 
 // num / den, correctly rounded, from a once-refined reciprocal r ~ 1/den shared by several numerators: the
@@ -232,7 +274,7 @@ __device__ __forceinline__ float div_by_recip(float num, float den, float r)
 // pixels lie near u = 0).  Only factors that are plain products are regrouped or precomputed per entry
 // (1/sx^3, 1/sy^3, (sx^2-sy^2)/(sx^2 sy^2), 0.5*alpha*(2a vx + (b+c) vy) = alpha*mx): a few ulp per term.
 // ---------------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool NEED_OP>
 __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
                                                               const uint32_t* __restrict__ list,
                                                               const ProjRec* __restrict__ proj,
@@ -265,6 +307,8 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     const int y = ty * kTile + ly;
     const bool inside = x < g.W && y < g.row_end;
     const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+    // after wave_sum8_packed the 8-lane group (lane >> 3) holds the total of record component bitrev3(lane >> 3)
+    const int part_slot = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
 
     float4 fin = make_float4(0.f, 0.f, 0.f, 0.f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
     if (inside) {
@@ -361,17 +405,16 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                     g_sx = (ga * e1.x) * ((e0.x * vxx + e0.y * vxy) + e0.z * vyy);   // main.cpp:657-659, :677
                     g_sy = (ga * e1.y) * ((e0.z * vxx - e0.y * vxy) + e0.x * vyy);   // main.cpp:660-662, :678
                     g_rot = (ga * e1.z) * ((e0.x - e0.z) * vx * vy - e0.w * (vxx - vyy)); // main.cpp:680-685
-                    g_op = gs * G;                                                   // main.cpp:703-704
+                    if (NEED_OP) g_op = gs * G;                                      // main.cpp:703-704
                     T *= (1.0f - alpha);                                             // main.cpp:707
                     alive = !(T < kMinThroughput);
                     if (COUNT) n_act++;
                 }
-                wave_sum9_to_lane63(g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
-                if (lane == 63) { // order of the record: pos.xy, sx, sy, rot, color.rgb, opacity (main.cpp:85-93)
-                    s_part[w][e][0] = make_float4(g_px, g_py, g_sx, g_sy);
-                    s_part[w][e][1] = make_float4(g_rot, g_r, g_g, g_b);
-                    s_part[w][e][2].x = g_op;
-                }
+                // order of the record: pos.xy, sx, sy, rot, color.rgb, opacity (main.cpp:85-93)
+                const float tot = wave_sum8_packed<NEED_OP>(g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
+                float* part = reinterpret_cast<float*>(&s_part[w][e][0]);
+                if ((lane & 7) == 0) part[part_slot] = tot;
+                if (NEED_OP && lane == 63) part[8] = g_op;
                 alive_mask = __ballot(alive);
             }
         }
@@ -380,6 +423,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         // one float-atomic burst per (tile, splat): 9 consecutive floats of grads[idx]
         for (int i = tid; i < cnt * 9; i += 256) {
             const int e = i / 9, k = i - e * 9;
+            if (!NEED_OP && k == 8) continue; // dSplats.opacity left at zero on request
             float v = 0.0f;
             bool any_w = false;
 #pragma unroll
@@ -439,15 +483,20 @@ hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list,
 
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
                                   const float4* image0, const float4* image_ref, float* grads,
-                                  double* tile_sqerr, Geometry g, PairCounters* counters, hipStream_t stream)
+                                  double* tile_sqerr, Geometry g, bool need_opacity_grad, PairCounters* counters,
+                                  hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
-    if (counters)
-        hipLaunchKernelGGL(raster_backward_kernel<true>, dim3(raster_grid(g.num_tiles)), dim3(256), 0, stream,
-                           tile_off, list, proj, image0, image_ref, grads, tile_sqerr, g, counters);
-    else
-        hipLaunchKernelGGL(raster_backward_kernel<false>, dim3(raster_grid(g.num_tiles)), dim3(256), 0, stream,
-                           tile_off, list, proj, image0, image_ref, grads, tile_sqerr, g, counters);
+    const dim3 grid(raster_grid(g.num_tiles)), block(256);
+#define S2D_LAUNCH_BWD(C, O)                                                                                       \
+    hipLaunchKernelGGL((raster_backward_kernel<C, O>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
+                       grads, tile_sqerr, g, counters)
+    if (counters) {
+        if (need_opacity_grad) S2D_LAUNCH_BWD(true, true); else S2D_LAUNCH_BWD(true, false);
+    } else {
+        if (need_opacity_grad) S2D_LAUNCH_BWD(false, true); else S2D_LAUNCH_BWD(false, false);
+    }
+#undef S2D_LAUNCH_BWD
     return hipGetLastError();
 }
 

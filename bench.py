@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--rebin-interval", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
+                    "to rehearse the multi-process path with several ranks sharing one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,13 +86,19 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the trainer has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()  # == local_rank on a full node; ranks share a GPU only in gloo rehearsals
+    if args.backend == "nccl" and world > torch.cuda.device_count():
+        sys.exit("RCCL needs one GPU per rank: %d ranks, %d GPUs" % (world, torch.cuda.device_count()))
+    torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=args.backend)
 
     W, H, n = args.width, args.height, args.splats
     r0, r1 = D.slab_rows(H, rank, world)
@@ -100,9 +108,10 @@ def main():
     torch.cuda.set_stream(stream)
     assert stream.cuda_stream != 0
     grads = torch.zeros(n * 9, dtype=torch.float32, device="cuda")
-    t = S2D.Trainer(W, H, n, device=local_rank, row_begin=r0, row_end=r1,
+    t = S2D.Trainer(W, H, n, device=device, row_begin=r0, row_end=r1,
                     rebin_interval=args.rebin_interval, stream=stream.cuda_stream)
     t.bind_grads(grads.data_ptr())
+    t.lean_backward = True  # optimizeOpacity is off (main.cpp:317): Adam never reads dSplats.opacity (main.cpp:735)
     t.set_target_synthetic()
     t.init()
 
@@ -169,9 +178,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic target ref(x,y)=(x/W,1-x/W,y/H); splats from the reference's init() seeds",
-            "config": {"workload": "%dx%d synthetic RGB, %d Gaussians, fp32 (BASELINE.json configs[3])" % (W, H, n),
+            "config": {"workload": "%dx%d synthetic RGB, %d Gaussians, fp32%s" % (W, H, n, " (BASELINE.json configs[3])" if (W, H, n) == (4096, 4096, 1000000) else ""),
                        "width": W, "height": H, "n_splats": n,
-                       "parallelism": "rowslab%d%s" % (world, "+rccl-allreduce-grads" if world > 1 else ""),
+                       "parallelism": "rowslab%d%s" % (world, ("+%s-allreduce-grads" % ("rccl" if args.backend == "nccl" else args.backend)) if world > 1 else ""),
                        "rebin_interval": args.rebin_interval},
             "mse_last": mse_last,
             "psnr_db_last": (10.0 * float(np.log10(255.0 ** 2 / mse_last)) if mse_last > 0 else None),

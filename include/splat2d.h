@@ -70,6 +70,12 @@ typedef enum s2d_status {
 /* s2d_step / s2d_adam_step flags */
 #define S2D_STEP_OPTIMIZE_OPACITY 0x1u /* the "Optimize opacity" checkbox, main.cpp:317, :735-738, :825 */
 
+/* s2d_backward flags */
+#define S2D_BWD_SKIP_OPACITY_GRAD 0x1u /* leave dSplats.opacity at zero.  The reference always accumulates it
+                                        * (main.cpp:704) but reads it only when "Optimize opacity" is on (main.cpp:735):
+                                        * a caller whose next s2d_adam_step runs without S2D_STEP_OPTIMIZE_OPACITY
+                                        * may skip it.  s2d_step does so by itself. */
+
 /* s2d_config.flags */
 #define S2D_CFG_COUNT_PAIRS 0x1u /* count visited / active pixel-splat pairs in the raster kernels (diagnostic) */
 
@@ -128,7 +134,7 @@ int s2d_get_image(s2d_ctx* ctx, float* rgba32f);
 
 /* Backward pass, main.cpp:548-712: accumulates this slab's contribution into the gradient buffer
  * (which s2d_adam_step / s2d_step re-zero after use, like main.cpp:550).  Needs s2d_forward first. */
-int s2d_backward(s2d_ctx* ctx);
+int s2d_backward(s2d_ctx* ctx, uint32_t flags);
 int s2d_get_grads(s2d_ctx* ctx, s2d_splat* dsplats);
 
 /* Adam + constraints + finite guard, main.cpp:714-785, on the current gradient buffer; then iterations++ (809). */

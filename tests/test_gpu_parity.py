@@ -427,3 +427,25 @@ def test_cpp_host_loop_prints_the_reference_trace():
                         "--optimize-opacity", "--opacity-from", "1"], capture_output=True, text=True, check=True)
     got = [float(l.split("mse")[1]) for l in r.stdout.strip().splitlines()]
     assert abs(got[10] - 1145.5531) / 1145.5531 < 1e-4
+
+
+def test_backward_skip_opacity_grad_flag():
+    """S2D_BWD_SKIP_OPACITY_GRAD leaves dSplats.opacity at zero and changes nothing else (main.cpp:704 vs :735)."""
+    o, t = make_pair(mini_target(), 2000, 3)
+    t.forward(); t.backward(skip_opacity_grad=True)
+    lean = t.get_grads().view(np.float32).reshape(-1, 9).astype(np.float64)
+    t.close()
+    o.forward()
+    _, dsum, dabs = o.backward_stats()
+    assert np.all(lean[:, 8] == 0)
+    nz = dabs[:, :8] > 0
+    assert (np.abs(lean[:, :8] - dsum[:, :8])[nz] / dabs[:, :8][nz]).max() <= 1e-6
+    # s2d_step without the opacity flag uses the lean kernel; with it, the full one: one step each still matches the oracle
+    for opacity in (False, True):
+        o2, t2 = make_pair(mini_target(), 2000, 3, opacity)
+        o2.step()
+        t2.step(1)
+        got = t2.get_splats().view(np.float32).reshape(-1, 9).astype(np.float64)
+        t2.close()
+        want = o2.splats.view(np.float32).reshape(-1, 9).astype(np.float64)
+        assert (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max() <= REL
