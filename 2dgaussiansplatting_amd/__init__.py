@@ -40,7 +40,7 @@ class _Config(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("width", C.c_int32), ("height", C.c_int32),
                 ("n_splats", C.c_int32), ("device", C.c_int32), ("row_begin", C.c_int32),
                 ("row_end", C.c_int32), ("training_rate", C.c_float), ("flags", C.c_uint32),
-                ("rebin_interval", C.c_int32), ("stream", C.c_void_p)]
+                ("rebin_interval", C.c_int32), ("rebin_margin", C.c_float), ("stream", C.c_void_p)]
 
 
 class _Stats(C.Structure):
@@ -122,7 +122,7 @@ class Trainer:
     """
 
     def __init__(self, width, height, n_splats, device=0, row_begin=0, row_end=0, training_rate=0.0,
-                 rebin_interval=0, count_pairs=False, stream=None):
+                 rebin_interval=0, rebin_margin=0.0, count_pairs=False, stream=None):
         self.L = load_library()
         self.W, self.H, self.n = int(width), int(height), int(n_splats)
         cfg = _Config()
@@ -132,6 +132,7 @@ class Trainer:
         cfg.training_rate = float(training_rate)
         cfg.flags = S2D_CFG_COUNT_PAIRS if count_pairs else 0
         cfg.rebin_interval = int(rebin_interval)
+        cfg.rebin_margin = float(rebin_margin)
         cfg.stream = stream
         h = C.c_void_p()
         rc = self.L.s2d_create(C.byref(cfg), C.byref(h))

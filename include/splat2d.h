@@ -89,7 +89,13 @@ typedef struct s2d_config {
     int32_t row_begin, row_end;
     float training_rate;    /* 0 -> 0.05f (main.cpp:715) */
     uint32_t flags;         /* S2D_CFG_* */
-    int32_t rebin_interval; /* iterations between re-binning of the tile lists; 0 -> library default */
+    /* Tile lists may be re-used across iterations: they are built from tile rectangles inflated by
+     * rebin_margin pixels, and every iteration a device-side check forces a rebuild BEFORE the raster runs if
+     * any splat's exact rectangle left its binned one, so results do not depend on these two knobs.
+     * rebin_interval: 0 -> library default (rebuild only when the check fires); 1 -> rebuild every iteration;
+     * K > 1 -> additionally rebuild at least every K iterations.  rebin_margin: 0 -> default (4 pixels). */
+    int32_t rebin_interval;
+    float rebin_margin;
     void* stream;           /* hipStream_t to queue work on; NULL -> the context creates its own */
 } s2d_config;
 

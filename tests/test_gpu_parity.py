@@ -350,7 +350,7 @@ def test_call_order_errors():
 # ---------------------------------------------------------------------------------------------
 # cached tile lists
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("lr,interval", [(0.0, 8), (4.0, 8), (0.0, 1000)])
+@pytest.mark.parametrize("lr,interval", [(0.0, 8), (4.0, 8), (0.0, 0), (4.0, 0)])
 def test_cached_tile_lists_stay_exact(lr, interval):
     """Tile lists are re-used for several iterations (rebin_interval > 1).  Lists are supersets and inclusion
     is decided per pixel from the CURRENT parameters, so every iteration's framebuffer must still be bit-exact
@@ -372,7 +372,7 @@ def test_cached_tile_lists_stay_exact(lr, interval):
     if lr == 0.0:
         assert st["rebins"] < 24 // 2   # lists really were re-used
     else:
-        assert st["rebins"] > 24 // interval  # unscheduled rebuilds happened
+        assert st["rebins"] > 24 // 8   # unscheduled rebuilds happened
 
 
 # ---------------------------------------------------------------------------------------------
