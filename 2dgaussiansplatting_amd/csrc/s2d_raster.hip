@@ -146,7 +146,8 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                 if (COUNT) n_vis += (wm >> lane) & 1ull;
                 if ((wm & alive_mask) == 0ull) continue;
                 if (COUNT) n_exec += (lane == 0);
-                if (((wm >> lane) & 1ull) && alive) { // main.cpp:511-521
+                // the scalar lane mask IS the predicate "pixel visited" (main.cpp:511-514): no per-lane bit test
+                if (__builtin_amdgcn_inverse_ballot_w64(wm) && alive) { // main.cpp:511-521
                     const float4 q0 = s_q0[e], q1 = s_q1[e];
                     float vx, vy;
                     const float G = gauss_at(px, py, q0.x, q0.y, q0.z, q0.w, q1.x, &vx, &vy);
@@ -369,9 +370,14 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                 if ((wm & alive_mask) == 0ull) continue;
                 touched |= 1ull << e;
                 if (COUNT) n_exec += (lane == 0);
-                float g_px = 0.f, g_py = 0.f, g_sx = 0.f, g_sy = 0.f, g_rot = 0.f;
-                float g_r = 0.f, g_g = 0.f, g_b = 0.f, g_op = 0.f;
-                if (((wm >> lane) & 1ull) && alive) { // main.cpp:595-605
+                // Lanes this splat does not visit (main.cpp:595-598) or whose pixel is already below the throughput
+                // cut-off (main.cpp:604) run the same instructions with alpha forced to 0: then c += T*c*0 and
+                // T *= 1 are exact no-ops and every gradient term below is a multiple of alpha, i.e. exactly 0 --
+                // no divergent region, no zero-initialisation of the nine partials.
+                const bool act = __builtin_amdgcn_inverse_ballot_w64(wm) && alive;
+                if (COUNT) n_act += act ? 1 : 0;
+                float g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op = 0.f;
+                {
                     const float4 q0 = s_q0[e], q1 = s_q1[e];
                     const float4 e0 = s_e0[e], e1 = s_e1[e];
                     // ---- the reference's operations, in its order (decides T, alive, the running colour) ----
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                     const float mx = q0.z * vx + q0.w * vy;                          // inv_cov * v
                     const float my = q0.w * vx + q1.x * vy;
                     const float G = gauss_from_d2(vx * mx + vy * my);                // main.cpp:609-610
-                    const float alpha = G * e1.w;                                    // main.cpp:611
+                    const float alpha = act ? G * e1.w : 0.0f;                       // main.cpp:611
                     const float Tr = T * q1.y, Tg = T * q1.z, Tb = T * q1.w;
                     cr += Tr * alpha;                                                // main.cpp:623-625
                     cg += Tg * alpha;
@@ -405,10 +411,9 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                     g_sx = (ga * e1.x) * ((e0.x * vxx + e0.y * vxy) + e0.z * vyy);   // main.cpp:657-659, :677
                     g_sy = (ga * e1.y) * ((e0.z * vxx - e0.y * vxy) + e0.x * vyy);   // main.cpp:660-662, :678
                     g_rot = (ga * e1.z) * ((e0.x - e0.z) * vx * vy - e0.w * (vxx - vyy)); // main.cpp:680-685
-                    if (NEED_OP) g_op = gs * G;                                      // main.cpp:703-704
+                    if (NEED_OP) g_op = act ? gs * G : 0.0f;                         // main.cpp:703-704
                     T *= (1.0f - alpha);                                             // main.cpp:707
                     alive = !(T < kMinThroughput);
-                    if (COUNT) n_act++;
                 }
                 // order of the record: pos.xy, sx, sy, rot, color.rgb, opacity (main.cpp:85-93)
                 const float tot = wave_sum8_packed<NEED_OP>(g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
