@@ -43,6 +43,7 @@ struct s2d_ctx {
     uint32_t* d_keys[2] = {nullptr, nullptr};
     uint32_t* d_vals[2] = {nullptr, nullptr};
     uint32_t* d_sort_temp = nullptr;
+    unsigned long long* d_wave_masks = nullptr; // 4 x u64 per listed pair: forward -> backward lane masks
     uint64_t pair_capacity = 0;
     uint32_t* d_tile_off = nullptr;
     uint32_t* d_list = nullptr; // == one of d_vals after the sort
@@ -126,13 +127,16 @@ int ensure_pair_capacity(s2d_ctx* c, uint64_t need)
         c->d_keys[k] = c->d_vals[k] = nullptr;
     }
     if (c->d_sort_temp) S2D_HIP(c, hipFree(c->d_sort_temp));
+    if (c->d_wave_masks) S2D_HIP(c, hipFree(c->d_wave_masks));
     c->d_sort_temp = nullptr;
+    c->d_wave_masks = nullptr;
     c->pair_capacity = 0;
     for (int k = 0; k < 2; k++) {
         S2D_HIP(c, dev_alloc(&c->d_keys[k], cap));
         S2D_HIP(c, dev_alloc(&c->d_vals[k], cap));
     }
     S2D_HIP(c, dev_alloc(&c->d_sort_temp, sort_temp_words((int64_t)cap)));
+    S2D_HIP(c, dev_alloc(&c->d_wave_masks, (size_t)cap * 4));
     c->pair_capacity = cap;
     return S2D_OK;
 }
@@ -185,7 +189,7 @@ int queue_forward(s2d_ctx* c)
     if (!c->have_target) return fail(c, S2D_E_STATE, "no target image set (s2d_set_target)");
     int rc = prepare_lists(c);
     if (rc != S2D_OK) return rc;
-    S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->g,
+    S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_wave_masks, c->g,
                                      (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
     c->have_forward = true;
     c->have_backward = false;
@@ -196,7 +200,8 @@ int queue_backward(s2d_ctx* c, bool need_opacity_grad)
 {
     if (!c->have_forward) return fail(c, S2D_E_STATE, "s2d_backward needs s2d_forward on the current parameters");
     const int slot = c->iterations % c->trace_cap;
-    S2D_HIP(c, launch_raster_backward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->d_grads,
+    S2D_HIP(c, launch_raster_backward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->d_wave_masks,
+                                      c->d_grads,
                                       c->d_tile_sqerr, c->g, need_opacity_grad,
                                       (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
     S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->stream));
@@ -322,7 +327,7 @@ void s2d_destroy(s2d_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         void* ptrs[] = {c->d_splats, c->d_adams, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
-                        c->d_sort_temp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_sqerr_trace,
+                        c->d_sort_temp, c->d_wave_masks, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_sqerr_trace,
                         c->d_status, c->d_counters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);

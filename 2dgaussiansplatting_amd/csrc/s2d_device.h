@@ -81,9 +81,11 @@ hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, 
 
 // raster (s2d_raster.hip)
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
-                                 float4* image0, Geometry g, PairCounters* counters, hipStream_t stream);
+                                 float4* image0, unsigned long long* wave_masks, Geometry g, PairCounters* counters,
+                                 hipStream_t stream);
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
-                                  const float4* image0, const float4* image_ref, float* grads,
+                                  const float4* image0, const float4* image_ref,
+                                  const unsigned long long* wave_masks, float* grads,
                                   double* tile_sqerr, Geometry g, bool need_opacity_grad, PairCounters* counters,
                                   hipStream_t stream);
 // Sums tile_sqerr[0..num_tiles) in a fixed order into *out.

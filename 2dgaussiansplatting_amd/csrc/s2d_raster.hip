@@ -8,6 +8,8 @@
 //     column range (solve_quadratic + int truncation, main.cpp:498-509) for 4 tile rows each, producing one
 //     64-bit lane mask per (entry, wave): bit l set <=> the reference's loops visit that pixel for that
 //     splat.  The quadratic is solved once per (entry, row), not per pixel.
+//     The forward kernel also stores these masks (32 B per staged pair); the backward kernel of the same
+//     iteration, which walks exactly the same batches, loads them instead of solving the quadratics again.
 //   * after the barrier lane l of every wave fetches the mask of entry l; a ballot of "mask != 0" is the
 //     set of entries that touch this wave at all, and the blend loop iterates over its set bits only
 //     (scalar bit tricks + v_readlane), skipping an entry with a scalar branch when no LIVE lane is covered.
@@ -94,7 +96,8 @@ template <bool COUNT>
 __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __restrict__ tile_off,
                                                              const uint32_t* __restrict__ list,
                                                              const ProjRec* __restrict__ proj,
-                                                             float4* __restrict__ image0, Geometry g,
+                                                             float4* __restrict__ image0,
+                                                             unsigned long long* __restrict__ wave_masks, Geometry g,
                                                              PairCounters* __restrict__ counters)
 {
     __shared__ float4 s_q0[B];
@@ -134,6 +137,8 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
             }
         }
         __syncthreads();
+        // keep the lane masks for the backward pass, which walks exactly these batches (32 B per staged pair)
+        if (se < cnt) wave_masks[(size_t)(base + se) * 4 + sub] = s_mask[sub * B + se];
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
         unsigned long long alive_mask = __ballot(alive);
         if (alive_mask != 0ull || COUNT) {
@@ -281,6 +286,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                                                               const ProjRec* __restrict__ proj,
                                                               const float4* __restrict__ image0,
                                                               const float4* __restrict__ image_ref,
+                                                              const unsigned long long* __restrict__ wave_masks,
                                                               float* __restrict__ grads,
                                                               double* __restrict__ tile_sqerr, Geometry g,
                                                               PairCounters* __restrict__ counters)
@@ -339,12 +345,12 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     for (uint32_t base = beg; base < end; base += B, par ^= 1) {
         const int cnt = (int)min((uint32_t)B, end - base);
         if (se < cnt) {
-            const uint32_t idx = list[base + se];
-            const ProjRec* r = proj + idx;
-            const float4 q0 = r->q0, q1 = r->q1, q2 = r->q2;
-            stage_masks(reinterpret_cast<uint32_t*>(s_mask), se, sub, q0, q1, __float_as_int(q2.y),
-                        __float_as_int(q2.z), ty * kTile, tx * kTile, g.W, g.row_end);
+            // the forward pass of this iteration staged the same batch and left its lane masks behind
+            s_mask[sub * B + se] = wave_masks[(size_t)(base + se) * 4 + sub];
             if (sub == 0) {
+                const uint32_t idx = list[base + se];
+                const ProjRec* r = proj + idx;
+                const float4 q0 = r->q0, q1 = r->q1, q2 = r->q2;
                 const float4 q3 = r->q3;
                 const float cosT = q2.w, sinT = q3.x, sx = q3.y, sy = q3.z;
                 const float sx2 = sx * sx, sy2 = sy * sy;
@@ -474,20 +480,22 @@ __global__ __launch_bounds__(1024) void sqerr_finalize_kernel(const double* __re
 static inline unsigned raster_grid(int num_tiles) { return (unsigned)(((num_tiles + 7) / 8) * 8); }
 
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
-                                 float4* image0, Geometry g, PairCounters* counters, hipStream_t stream)
+                                 float4* image0, unsigned long long* wave_masks, Geometry g, PairCounters* counters,
+                                 hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
     if (counters)
         hipLaunchKernelGGL(raster_forward_kernel<true>, dim3(raster_grid(g.num_tiles)), dim3(256), 0, stream, tile_off,
-                           list, proj, image0, g, counters);
+                           list, proj, image0, wave_masks, g, counters);
     else
         hipLaunchKernelGGL(raster_forward_kernel<false>, dim3(raster_grid(g.num_tiles)), dim3(256), 0, stream,
-                           tile_off, list, proj, image0, g, counters);
+                           tile_off, list, proj, image0, wave_masks, g, counters);
     return hipGetLastError();
 }
 
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
-                                  const float4* image0, const float4* image_ref, float* grads,
+                                  const float4* image0, const float4* image_ref,
+                                  const unsigned long long* wave_masks, float* grads,
                                   double* tile_sqerr, Geometry g, bool need_opacity_grad, PairCounters* counters,
                                   hipStream_t stream)
 {
@@ -495,7 +503,7 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
 #define S2D_LAUNCH_BWD(C, O)                                                                                       \
     hipLaunchKernelGGL((raster_backward_kernel<C, O>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
-                       grads, tile_sqerr, g, counters)
+                       wave_masks, grads, tile_sqerr, g, counters)
     if (counters) {
         if (need_opacity_grad) S2D_LAUNCH_BWD(true, true); else S2D_LAUNCH_BWD(true, false);
     } else {
