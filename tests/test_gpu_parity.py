@@ -449,3 +449,127 @@ def test_backward_skip_opacity_grad_flag():
         t2.close()
         want = o2.splats.view(np.float32).reshape(-1, 9).astype(np.float64)
         assert (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max() <= REL
+
+
+# ---------------------------------------------------------------------------------------------
+# more edge cases
+# ---------------------------------------------------------------------------------------------
+def _run_pair(W, H, splats, tgt=None, check_grads=True):
+    tgt = O.synthetic_target(W, H) if tgt is None else tgt
+    n = len(splats)
+    o = O.OracleTrainer(tgt, n)
+    o.splats[:] = splats
+    want = o.forward().copy()
+    with S2D.Trainer(W, H, n) as t:
+        t.set_target(tgt)
+        t.set_splats(o.splats.view(S2D.SPLAT_DTYPE))
+        t.forward()
+        got = t.get_image()
+        assert got.tobytes() == want.tobytes()
+        if check_grads:
+            t.backward()
+            grad_check(t.get_grads(), o)
+        return t.stats()
+
+
+def test_image_covering_splats_grow_the_pair_buffers():
+    """Every splat covers every tile (sigma = 300 on 640x480): the pair count (n * tiles) outgrows the initial
+    capacity, lists are 1200 entries per tile, low opacity keeps all of them alive."""
+    W, H, n = 640, 480, 1200
+    rng = np.random.default_rng(21)
+    s = np.zeros(n, dtype=O.SPLAT_DTYPE)
+    s["pos"][:, 0] = rng.uniform(0, W - 1, n)
+    s["pos"][:, 1] = rng.uniform(0, H - 1, n)
+    s["sx"] = rng.uniform(250, 400, n)
+    s["sy"] = rng.uniform(250, 400, n)
+    s["rot"] = rng.uniform(0, np.pi, n)
+    s["color"] = rng.uniform(0, 1, (n, 3))
+    s["opacity"] = 0.1
+    st = _run_pair(W, H, s, check_grads=False)
+    assert st["pairs_binned"] == n * 40 * 30
+    assert st["pairs_capacity"] >= st["pairs_binned"]
+
+
+def test_low_opacity_deep_stacks():
+    """opacity 0.1: ~50 splats contribute to every pixel before the 1/256 cut-off; gradients of deep stacks."""
+    W, H, n = 160, 120, 3000
+    rng = np.random.default_rng(22)
+    s = np.zeros(n, dtype=O.SPLAT_DTYPE)
+    s["pos"][:, 0] = rng.uniform(0, W - 1, n)
+    s["pos"][:, 1] = rng.uniform(0, H - 1, n)
+    s["sx"] = rng.uniform(4, 12, n)
+    s["sy"] = rng.uniform(4, 12, n)
+    s["rot"] = rng.uniform(0, np.pi, n)
+    s["color"] = rng.uniform(0, 1, (n, 3))
+    s["opacity"] = rng.choice([0.1, 0.15, 0.3], n)
+    _run_pair(W, H, s, tgt=O.target_rgba32f(O.load_s2di(MINI))[:H, :W].copy())
+
+
+def test_minimum_size_splats_and_pixel_centres():
+    """sx = sy = 1 (the clamp floor, main.cpp:744-745), positions exactly on pixel centres / corners / borders:
+    alpha reaches exactly 1 at a centre (1 - alpha + 1e-15 = 1e-15 in the backward pass, main.cpp:628)."""
+    W, H = 48, 32
+    pts = [(x + dx, y + dy) for x in (0, 15, 16, 31, 47) for y in (0, 15, 16, 31) for dx, dy in ((0.5, 0.5), (0.0, 0.0))]
+    pts = [(min(px, W - 1), min(py, H - 1)) for px, py in pts]
+    n = len(pts)
+    s = np.zeros(n, dtype=O.SPLAT_DTYPE)
+    s["pos"] = np.array(pts, dtype=np.float32)
+    s["sx"] = 1.0
+    s["sy"] = 1.0
+    s["rot"] = np.linspace(0, 3, n)
+    s["color"] = np.linspace(0.1, 0.9, n)[:, None]
+    s["opacity"] = 1.0
+    tgt = O.synthetic_target(W, H)
+    o = O.OracleTrainer(tgt, n)
+    o.splats[:] = s
+    want = o.forward().copy()
+    wg = o.backward().copy()
+    with S2D.Trainer(W, H, n) as t:
+        t.set_target(tgt)
+        t.set_splats(s.view(S2D.SPLAT_DTYPE))
+        t.forward()
+        assert t.get_image().tobytes() == want.tobytes()
+        t.backward()
+        g = t.get_grads().view(np.float32).reshape(-1, 9)
+    w = wg.view(np.float32).reshape(-1, 9)
+    # where alpha == 1 exactly the reference divides by 1e-15: huge but finite terms; same magnitudes on both sides
+    assert np.isfinite(g).all() == np.isfinite(w).all()
+    fin = np.isfinite(w) & np.isfinite(g)
+    np.testing.assert_allclose(g[fin], w[fin], rtol=1e-3, atol=1e-3 * np.abs(w[fin]).max())
+
+
+def test_splats_entirely_off_image_and_single_row_image():
+    W, H = 200, 1
+    s = random_splats(50, W, 4, 31)
+    s["pos"][:, 1] = 0
+    _run_pair(W, H, s)
+    W, H = 64, 64
+    s = random_splats(40, W, H, 32)
+    s["pos"][:20] = [-500.0, 30.0]      # far outside on the left: the clamp would normally prevent this
+    s["pos"][20:30] = [30.0, 5000.0]
+    st = _run_pair(W, H, s)
+    assert st["pairs_binned"] < 40 * 16
+
+
+def test_checkpoint_roundtrip_resumes_identically():
+    """State that crosses the boundary (main.cpp:272-278) is enough to resume: same forward image bit for bit."""
+    tgt = mini_target()
+    with S2D.Trainer(268, 213, 1500) as a:
+        a.set_target(tgt)
+        a.init()
+        a.step(7)
+        sp, (ad, b1, b2, it) = a.get_splats(), a.get_adam()
+        a.forward()
+        img_a = a.get_image()
+        a.step(3)
+        ref = a.get_splats()
+    with S2D.Trainer(268, 213, 1500) as b:
+        b.set_target(tgt)
+        b.set_splats(sp)
+        b.set_adam(ad, b1, b2, it)
+        b.forward()
+        assert b.get_image().tobytes() == img_a.tobytes()
+        b.step(3)
+        got = b.get_splats()
+        assert b.stats()["iterations"] == 10
+    np.testing.assert_allclose(got.view(np.float32), ref.view(np.float32), rtol=1e-4, atol=1e-4)
