@@ -33,6 +33,7 @@ struct Options {
     int restart_at = -1;        // press "Restart" before this iteration (main.cpp:828-831)
     bool quiet = false;
     std::string out_ppm;
+    std::string load_ckpt, save_ckpt; // the five objects of main.cpp:272-278: splats, splatAdams, beta1t, beta2t, iterations
     int device = 0;
     int rebin_interval = 0;
 };
@@ -55,6 +56,42 @@ bool load_s2di(const std::string& path, int* w, int* h, std::vector<uint8_t>* rg
     return ok;
 }
 
+// Binary PPM (P6, maxval 255) as an alternative to the .s2di fixtures.
+bool load_ppm(const std::string& path, int* w, int* h, std::vector<uint8_t>* rgb)
+{
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char magic[3] = {0, 0, 0};
+    int maxv = 0;
+    bool ok = std::fscanf(f, "%2s", magic) == 1 && std::strcmp(magic, "P6") == 0;
+    for (int field = 0; ok && field < 3; field++) {
+        int c = std::fgetc(f);
+        while (c == ' ' || c == '\n' || c == '\r' || c == '\t' || c == '#') {
+            if (c == '#') while (c != '\n' && c != EOF) c = std::fgetc(f);
+            c = std::fgetc(f);
+        }
+        std::ungetc(c, f);
+        int v = 0;
+        ok = std::fscanf(f, "%d", &v) == 1 && v > 0;
+        (field == 0 ? *w : field == 1 ? *h : maxv) = v;
+    }
+    ok = ok && maxv == 255 && std::fgetc(f) != EOF;
+    if (ok) {
+        rgb->resize((size_t)*w * *h * 3);
+        ok = std::fread(rgb->data(), 1, rgb->size(), f) == rgb->size();
+    }
+    std::fclose(f);
+    return ok;
+}
+
+// Checkpoint = the state main() keeps between frames (main.cpp:272-278), in the reference's own layouts.
+struct CkptHeader {
+    char magic[4];      // "S2DC"
+    uint32_t n_splats, width, height;
+    float beta1t, beta2t;
+    int32_t iterations;
+};
+
 bool write_ppm(const std::string& path, int w, int h, const std::vector<float>& rgba)
 {
     FILE* f = std::fopen(path.c_str(), "wb");
@@ -76,8 +113,9 @@ bool write_ppm(const std::string& path, int w, int h, const std::vector<float>& 
 int usage()
 {
     std::fprintf(stderr,
-                 "usage: splat2d_train (--image file.s2di | --synthetic WxH) [--splats N] [--iters K] [--batch B]\n"
+                 "usage: splat2d_train (--image file.s2di|file.ppm | --synthetic WxH) [--splats N] [--iters K] [--batch B]\n"
                  "                     [--optimize-opacity [--opacity-from IT]] [--restart-at IT] [--out-ppm file]\n"
+                 "                     [--load-checkpoint file] [--save-checkpoint file]\n"
                  "                     [--device D] [--rebin-interval R] [--quiet]\n");
     return 2;
 }
@@ -112,6 +150,8 @@ int main(int argc, char** argv)
         else if (a == "--opacity-from") o.opacity_from = std::atoi(next("--opacity-from"));
         else if (a == "--restart-at") o.restart_at = std::atoi(next("--restart-at"));
         else if (a == "--out-ppm") o.out_ppm = next("--out-ppm");
+        else if (a == "--load-checkpoint") o.load_ckpt = next("--load-checkpoint");
+        else if (a == "--save-checkpoint") o.save_ckpt = next("--save-checkpoint");
         else if (a == "--device") o.device = std::atoi(next("--device"));
         else if (a == "--rebin-interval") o.rebin_interval = std::atoi(next("--rebin-interval"));
         else if (a == "--quiet") o.quiet = true;
@@ -124,7 +164,8 @@ int main(int argc, char** argv)
     std::vector<float> imageRef;
     if (!o.image.empty()) {
         std::vector<uint8_t> rgb;
-        if (!load_s2di(o.image, &W, &H, &rgb)) {
+        const bool is_ppm = o.image.size() > 4 && o.image.substr(o.image.size() - 4) == ".ppm";
+        if (!(is_ppm ? load_ppm(o.image, &W, &H, &rgb) : load_s2di(o.image, &W, &H, &rgb))) {
             std::fprintf(stderr, "cannot read %s\n", o.image.c_str());
             return 1;
         }
@@ -150,6 +191,26 @@ int main(int argc, char** argv)
     CK(s2d_init_splats(ctx)); // init(); main.cpp:307
 
     int iterations = 0; // main.cpp:278
+    if (!o.load_ckpt.empty()) {
+        FILE* f = std::fopen(o.load_ckpt.c_str(), "rb");
+        CkptHeader h;
+        std::vector<s2d_splat> sp((size_t)o.n_splats);
+        std::vector<s2d_splat_adam> ad((size_t)o.n_splats);
+        const bool ok = f && std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, "S2DC", 4) == 0 &&
+                        (int)h.n_splats == o.n_splats && (int)h.width == W && (int)h.height == H &&
+                        std::fread(sp.data(), sizeof(s2d_splat), sp.size(), f) == sp.size() &&
+                        std::fread(ad.data(), sizeof(s2d_splat_adam), ad.size(), f) == ad.size();
+        if (f) std::fclose(f);
+        if (!ok) {
+            std::fprintf(stderr, "cannot load checkpoint %s (wrong size or format)\n", o.load_ckpt.c_str());
+            s2d_destroy(ctx);
+            return 1;
+        }
+        CK(s2d_set_splats(ctx, sp.data()));
+        CK(s2d_set_adam(ctx, ad.data(), h.beta1t, h.beta2t, h.iterations));
+        iterations = h.iterations;
+        o.iters += iterations; // --iters counts iterations to run from the checkpoint
+    }
     std::vector<double> mse((size_t)o.batch);
     const auto t0 = std::chrono::steady_clock::now();
     while (iterations < o.iters) { // while (pr::NextFrame() == false), main.cpp:334
@@ -171,6 +232,21 @@ int main(int argc, char** argv)
     std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats)\n", iterations, secs,
                  secs > 0 ? iterations / secs : 0.0, W, H, o.n_splats);
 
+    if (!o.save_ckpt.empty()) {
+        CkptHeader h;
+        std::memcpy(h.magic, "S2DC", 4);
+        h.n_splats = (uint32_t)o.n_splats; h.width = (uint32_t)W; h.height = (uint32_t)H;
+        std::vector<s2d_splat> sp((size_t)o.n_splats);
+        std::vector<s2d_splat_adam> ad((size_t)o.n_splats);
+        CK(s2d_get_splats(ctx, sp.data()));
+        CK(s2d_get_adam(ctx, ad.data(), &h.beta1t, &h.beta2t, &h.iterations));
+        FILE* f = std::fopen(o.save_ckpt.c_str(), "wb");
+        const bool ok = f && std::fwrite(&h, sizeof(h), 1, f) == 1 &&
+                        std::fwrite(sp.data(), sizeof(s2d_splat), sp.size(), f) == sp.size() &&
+                        std::fwrite(ad.data(), sizeof(s2d_splat_adam), ad.size(), f) == ad.size();
+        if (f) std::fclose(f);
+        if (!ok) std::fprintf(stderr, "cannot write %s\n", o.save_ckpt.c_str());
+    }
     if (!o.out_ppm.empty()) {
         std::vector<float> image0((size_t)W * H * 4);
         CK(s2d_forward(ctx));

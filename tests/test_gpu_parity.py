@@ -573,3 +573,30 @@ def test_checkpoint_roundtrip_resumes_identically():
         got = b.get_splats()
         assert b.stats()["iterations"] == 10
     np.testing.assert_allclose(got.view(np.float32), ref.view(np.float32), rtol=1e-4, atol=1e-4)
+
+
+def test_cpp_host_checkpoint_and_ppm(tmp_path):
+    """splat2d_train: PPM input, --save-checkpoint / --load-checkpoint continue the same trajectory, PPM export."""
+    import subprocess
+    exe = S2D._build.build_host_program()
+    rgb = O.load_s2di(MINI)
+    ppm = tmp_path / "mini.ppm"
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n# decoded fixture\n%d %d\n255\n" % (rgb.shape[1], rgb.shape[0]) + rgb.tobytes())
+    ck = str(tmp_path / "ck.bin")
+    out = str(tmp_path / "out.ppm")
+    a = subprocess.run([exe, "--image", str(ppm), "--splats", "1024", "--iters", "6", "--save-checkpoint", ck],
+                       capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    assert a[0] == "0 itr, mse 5934.9042"
+    b = subprocess.run([exe, "--image", MINI, "--splats", "1024", "--iters", "4", "--load-checkpoint", ck, "--out-ppm", out],
+                       capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    assert [int(l.split()[0]) for l in b] == [6, 7, 8, 9]
+    full = subprocess.run([exe, "--image", MINI, "--splats", "1024", "--iters", "10"], capture_output=True, text=True,
+                          check=True).stdout.strip().splitlines()
+    np.testing.assert_allclose([float(l.split("mse")[1]) for l in a + b], [float(l.split("mse")[1]) for l in full], rtol=2e-5)
+    hdr = open(out, "rb").read(15)
+    assert hdr.startswith(b"P6\n268 213\n255\n") and os.path.getsize(out) == 15 + 268 * 213 * 3
+    # restart button: the trace starts over from the init() state
+    r = subprocess.run([exe, "--image", MINI, "--splats", "1024", "--iters", "5", "--restart-at", "3"], capture_output=True,
+                       text=True, check=True).stdout.strip().splitlines()
+    assert r[3].endswith("mse 5934.9042") and r[0].endswith("mse 5934.9042")
