@@ -600,3 +600,29 @@ def test_cpp_host_checkpoint_and_ppm(tmp_path):
     r = subprocess.run([exe, "--image", MINI, "--splats", "1024", "--iters", "5", "--restart-at", "3"], capture_output=True,
                        text=True, check=True).stdout.strip().splitlines()
     assert r[3].endswith("mse 5934.9042") and r[0].endswith("mse 5934.9042")
+
+
+def test_against_committed_oracle_golden():
+    """Same check as the live-oracle tests, against the committed bundle tests/golden/oracle_cfg1_it5.npz
+    (BASELINE configs[0]: mini image, N = 2000, state after 5 iterations)."""
+    z = np.load(os.path.join(O.GOLDEN, "oracle_cfg1_it5.npz"))
+    with S2D.Trainer(268, 213, 2000, count_pairs=True) as t:
+        t.set_target(mini_target())
+        t.set_splats(z["splats"].view(S2D.SPLAT_DTYPE))
+        t.set_adam(z["adams"].view(S2D.ADAM_DTYPE), z["beta1t"][0], z["beta2t"][0], int(z["iterations"]))
+        t.forward()
+        img = t.get_image()
+        assert hashlib.sha256(img.tobytes()).hexdigest() == str(z["image_sha256"])
+        assert img[100:104].tobytes() == z["image_rows_100_103"].tobytes()
+        t.backward()
+        g = t.get_grads().view(np.float32).reshape(-1, 9).astype(np.float64)
+        assert t.stats()["bwd_active"] == int(z["active_pairs"])
+        assert abs(t.mse() - float(z["mse"])) <= 1e-9 * float(z["mse"])
+        dsum, dabs, w = z["grads_exact_sum"], z["grads_abs_sum"].astype(np.float64), z["grads_fp32"].astype(np.float64)
+        nz = dabs > 0
+        assert (np.abs(g - dsum)[nz] / dabs[nz]).max() <= 1e-6
+        assert (np.abs(g - w)[nz] / np.maximum(np.abs(w[nz]), 0.02 * dabs[nz])).max() <= REL
+        t.adam_step()
+        got = t.get_splats().view(np.float32).reshape(-1, 9).astype(np.float64)
+    want = z["splats_after_step"].view(np.float32).reshape(-1, 9).astype(np.float64)
+    assert (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max() <= REL

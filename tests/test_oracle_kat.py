@@ -38,9 +38,32 @@ def fmt(v):
     return "%.4f" % v
 
 
+import json
+
+KAT = json.load(open(os.path.join(O.GOLDEN, "survey_appendix_c.json")))
+
+
 def test_fixture_hashes():
-    for path, want in ((MINI, "84fc7f3b4eba07ae"), (FULL, "ba7ed1b221888ba2")):
-        assert hashlib.sha256(O.load_s2di(path).tobytes()).hexdigest()[:16] == want
+    for name, want in KAT["fixtures_sha256_16"].items():
+        assert hashlib.sha256(O.load_s2di(os.path.join(O.GOLDEN, name)).tobytes()).hexdigest()[:16] == want
+
+
+def test_kat_file_matches_the_traces_asserted_below():
+    """The literal digits in this file and tests/golden/survey_appendix_c.json are the same vectors."""
+    assert KAT["mini_n1024_as_shipped"]["mse_at"]["299"] == "84.7616"
+    assert KAT["mini_n1024_it0_framebuffer"]["sha256_16_rgba32f"] == "6f025c573a78c6b8"
+    assert KAT["native_535x426_n50000"]["mse_at"]["19"] == "501.1730"
+
+
+def test_committed_oracle_golden_is_current():
+    """tests/golden/oracle_cfg1_it5.npz (made by tools/make_oracle_golden.py) is what the oracle produces now."""
+    z = np.load(os.path.join(O.GOLDEN, "oracle_cfg1_it5.npz"))
+    t = O.OracleTrainer(O.target_rgba32f(O.load_s2di(MINI)), 2000)
+    tr = [t.step()[1] for _ in range(5)]
+    assert np.array_equal(np.array(tr), z["mse_trace_0_4"])
+    assert t.splats.tobytes() == z["splats"].tobytes() and t.adams.tobytes() == z["adams"].tobytes()
+    assert hashlib.sha256(t.forward().tobytes()).hexdigest() == str(z["image_sha256"])
+    assert fmt(tr[0]) == KAT["mini_n2000_cfg1"]["mse_at"]["0"] and fmt(tr[2]) == KAT["mini_n2000_cfg1"]["mse_at"]["2"]
 
 
 def test_init_positions_n1024():
