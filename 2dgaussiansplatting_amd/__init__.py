@@ -47,7 +47,7 @@ class _Stats(C.Structure):
     _fields_ = [("pairs_binned", C.c_uint64), ("pairs_capacity", C.c_uint64), ("rebins", C.c_uint64),
                 ("fwd_visited", C.c_uint64), ("fwd_active", C.c_uint64), ("bwd_visited", C.c_uint64),
                 ("bwd_active", C.c_uint64), ("fwd_staged", C.c_uint64), ("bwd_staged", C.c_uint64),
-                ("fwd_wave_execs", C.c_uint64), ("bwd_wave_execs", C.c_uint64),
+                ("fwd_wave_execs", C.c_uint64), ("bwd_wave_execs", C.c_uint64), ("bwd_lane_hist", C.c_uint64 * 65),
                 ("iterations", C.c_int32), ("first_nonfinite_iteration", C.c_int32)]
 
 
@@ -259,7 +259,9 @@ class Trainer:
     def stats(self):
         s = _Stats()
         self._ck(self.L.s2d_get_stats(self._h, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in _Stats._fields_}
+        out = {k: getattr(s, k) for k, _ in _Stats._fields_}
+        out["bwd_lane_hist"] = list(s.bwd_lane_hist)
+        return out
 
     def tile_lists(self):
         st = self.stats()

@@ -546,6 +546,7 @@ int s2d_get_stats(s2d_ctx* c, s2d_stats* out)
     out->bwd_visited = pc.bwd_visited; out->bwd_active = pc.bwd_active;
     out->fwd_staged = pc.fwd_staged; out->bwd_staged = pc.bwd_staged;
     out->fwd_wave_execs = pc.fwd_wave_execs; out->bwd_wave_execs = pc.bwd_wave_execs;
+    for (int k = 0; k < 65; k++) out->bwd_lane_hist[k] = pc.bwd_lane_hist[k];
     out->iterations = c->iterations;
     out->first_nonfinite_iteration = c->h_status->nonfinite ? c->h_status->first_nonfinite_iter : -1;
     return S2D_OK;

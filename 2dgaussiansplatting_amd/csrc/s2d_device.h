@@ -38,6 +38,7 @@ struct Geometry {
 struct PairCounters {
     unsigned long long fwd_visited, fwd_active, bwd_visited, bwd_active, fwd_staged, bwd_staged, fwd_wave_execs,
         bwd_wave_execs;
+    unsigned long long bwd_lane_hist[65]; // executed (wave, entry) pairs by number of active lanes
 };
 
 // Device-resident status word(s), written by kernels, read by the host at synchronisation points.

@@ -381,7 +381,11 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                 // T *= 1 are exact no-ops and every gradient term below is a multiple of alpha, i.e. exactly 0 --
                 // no divergent region, no zero-initialisation of the nine partials.
                 const bool act = __builtin_amdgcn_inverse_ballot_w64(wm) && alive;
-                if (COUNT) n_act += act ? 1 : 0;
+                if (COUNT) {
+                    n_act += act ? 1 : 0;
+                    const int na = __popcll(__ballot(act));
+                    if (lane == 0) atomicAdd(&counters->bwd_lane_hist[na], 1ull);
+                }
                 float g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op = 0.f;
                 {
                     const float4 q0 = s_q0[e], q1 = s_q1[e];

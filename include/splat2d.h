@@ -107,6 +107,7 @@ typedef struct s2d_stats {
     uint64_t bwd_visited, bwd_active;
     uint64_t fwd_staged, bwd_staged;  /* list entries the raster kernels actually staged (after tile retirement) */
     uint64_t fwd_wave_execs, bwd_wave_execs; /* (wave, entry) pairs whose blend body ran (>= 1 live lane covered) */
+    uint64_t bwd_lane_hist[65];              /* ... of the backward pass, by number of active lanes (0..64) */
     int32_t iterations;        /* == `iterations`, main.cpp:278 */
     int32_t first_nonfinite_iteration; /* -1 if none */
 } s2d_stats;

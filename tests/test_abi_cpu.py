@@ -46,6 +46,7 @@ def test_struct_layouts_match_header():
         printf("%zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(s2d_splat), sizeof(s2d_splat_adam), sizeof(s2d_config),
                sizeof(s2d_stats), offsetof(s2d_config, stream), offsetof(s2d_config, training_rate),
                offsetof(s2d_stats, iterations), offsetof(s2d_stats, fwd_wave_execs));
+        
         return 0;
     }'''
     with tempfile.TemporaryDirectory() as d:

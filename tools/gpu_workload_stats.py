@@ -25,3 +25,8 @@ for d in ("fwd", "bwd"):
     print("%s: staged %.1f/tile (%.0f%% of list)  visited %.1f/px  active %.1f/px  wave-execs %.1f/wave  lanes/exec %.1f" % (
         d, st[d + "_staged"] / tiles, 100.0 * st[d + "_staged"] / max(st["pairs_binned"], 1), st[d + "_visited"] / px,
         st[d + "_active"] / px, st[d + "_wave_execs"] / (tiles * 4), st[d + "_active"] / max(st[d + "_wave_execs"], 1)))
+h = np.array(st["bwd_lane_hist"], dtype=np.float64)
+tot = h.sum()
+cum = np.cumsum(h) / tot
+work = np.cumsum(h * np.arange(65)) / (h * np.arange(65)).sum()
+print("bwd execs by active lanes: " + "  ".join("<=%d: %.0f%% of execs, %.0f%% of lane-work" % (k, 100 * cum[k], 100 * work[k]) for k in (4, 8, 16, 24, 32, 48, 63)))
