@@ -56,10 +56,11 @@ def build_host_program(force=False, verbose=False):
     src = os.path.join(HOST_DIR, "splat2d_train.cpp")
     if not os.path.exists(src):
         return None
-    deps = [src, os.path.join(ROOT, "include", "splat2d.h"), LIB_PATH]
+    deps = [src, os.path.join(HOST_DIR, "image_io.h"), os.path.join(HOST_DIR, "overlay.h"),
+            os.path.join(ROOT, "include", "splat2d.h"), LIB_PATH]
     if force or _stale(TRAIN_BIN, deps):
         cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", TRAIN_BIN, src,
-               "-L", LIB_DIR, "-lsplat2d_hip", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+               "-L", LIB_DIR, "-lsplat2d_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -18,12 +18,14 @@
 #include <string>
 #include <vector>
 
+#include "image_io.h"
+#include "overlay.h"
 #include "splat2d.h"
 
 namespace {
 
 struct Options {
-    std::string image;          // .s2di fixture (raw RGB8, see tools/make_image_fixtures.py)
+    std::string image;          // .s2di fixture (raw RGB8, see tools/make_image_fixtures.py), binary .ppm or .png
     int syn_w = 0, syn_h = 0;   // --synthetic WxH
     int n_splats = 1024;        // NSplat, main.cpp:271
     int iters = 300;
@@ -32,57 +34,15 @@ struct Options {
     int opacity_from = 0;       // iteration from which the flag is on (the GUI checkbox can be ticked mid-run)
     int restart_at = -1;        // press "Restart" before this iteration (main.cpp:828-831)
     bool quiet = false;
-    std::string out_ppm;
+    std::string out_image;      // --out-image file.(png|ppm|s2di): image0 after the last iteration (main.cpp:794)
+    std::string overlay;        // --overlay file: image0 upscaled by overlay_scale with the splat debug drawing (main.cpp:441-485)
+    int overlay_scale = 2;      // viewScale, main.cpp:822
+    int overlay_stride = 1;     // draw every k-th splat
+    std::string convert_in, convert_out; // --convert in out: image conversion only (no GPU)
     std::string load_ckpt, save_ckpt; // the five objects of main.cpp:272-278: splats, splatAdams, beta1t, beta2t, iterations
     int device = 0;
     int rebin_interval = 0;
 };
-
-bool load_s2di(const std::string& path, int* w, int* h, std::vector<uint8_t>* rgb)
-{
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) return false;
-    char magic[4];
-    uint32_t hdr[3];
-    bool ok = std::fread(magic, 1, 4, f) == 4 && std::memcmp(magic, "S2DI", 4) == 0 && std::fread(hdr, 4, 3, f) == 3 &&
-              hdr[2] == 3;
-    if (ok) {
-        *w = (int)hdr[0];
-        *h = (int)hdr[1];
-        rgb->resize((size_t)hdr[0] * hdr[1] * 3);
-        ok = std::fread(rgb->data(), 1, rgb->size(), f) == rgb->size();
-    }
-    std::fclose(f);
-    return ok;
-}
-
-// Binary PPM (P6, maxval 255) as an alternative to the .s2di fixtures.
-bool load_ppm(const std::string& path, int* w, int* h, std::vector<uint8_t>* rgb)
-{
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) return false;
-    char magic[3] = {0, 0, 0};
-    int maxv = 0;
-    bool ok = std::fscanf(f, "%2s", magic) == 1 && std::strcmp(magic, "P6") == 0;
-    for (int field = 0; ok && field < 3; field++) {
-        int c = std::fgetc(f);
-        while (c == ' ' || c == '\n' || c == '\r' || c == '\t' || c == '#') {
-            if (c == '#') while (c != '\n' && c != EOF) c = std::fgetc(f);
-            c = std::fgetc(f);
-        }
-        std::ungetc(c, f);
-        int v = 0;
-        ok = std::fscanf(f, "%d", &v) == 1 && v > 0;
-        (field == 0 ? *w : field == 1 ? *h : maxv) = v;
-    }
-    ok = ok && maxv == 255 && std::fgetc(f) != EOF;
-    if (ok) {
-        rgb->resize((size_t)*w * *h * 3);
-        ok = std::fread(rgb->data(), 1, rgb->size(), f) == rgb->size();
-    }
-    std::fclose(f);
-    return ok;
-}
 
 // Checkpoint = the state main() keeps between frames (main.cpp:272-278), in the reference's own layouts.
 struct CkptHeader {
@@ -92,29 +52,13 @@ struct CkptHeader {
     int32_t iterations;
 };
 
-bool write_ppm(const std::string& path, int w, int h, const std::vector<float>& rgba)
-{
-    FILE* f = std::fopen(path.c_str(), "wb");
-    if (!f) return false;
-    std::fprintf(f, "P6\n%d %d\n255\n", w, h);
-    std::vector<uint8_t> row((size_t)w * 3);
-    for (int y = 0; y < h; y++) {
-        for (int x = 0; x < w; x++)
-            for (int c = 0; c < 3; c++) {
-                float v = rgba[((size_t)y * w + x) * 4 + c] * 255.0f + 0.5f;
-                row[(size_t)x * 3 + c] = (uint8_t)(v < 0.0f ? 0.0f : (v > 255.0f ? 255.0f : v));
-            }
-        std::fwrite(row.data(), 1, row.size(), f);
-    }
-    std::fclose(f);
-    return true;
-}
-
 int usage()
 {
     std::fprintf(stderr,
-                 "usage: splat2d_train (--image file.s2di|file.ppm | --synthetic WxH) [--splats N] [--iters K] [--batch B]\n"
-                 "                     [--optimize-opacity [--opacity-from IT]] [--restart-at IT] [--out-ppm file]\n"
+                 "usage: splat2d_train (--image file.s2di|.ppm|.png | --synthetic WxH) [--splats N] [--iters K] [--batch B]\n"
+                 "                     [--optimize-opacity [--opacity-from IT]] [--restart-at IT] [--out-image file.png|.ppm]\n"
+                 "                     [--overlay file [--overlay-scale S] [--overlay-stride K]]\n"
+                 "       splat2d_train --convert in.(s2di|ppm|png) out.(s2di|ppm|png)\n"
                  "                     [--load-checkpoint file] [--save-checkpoint file]\n"
                  "                     [--device D] [--rebin-interval R] [--quiet]\n");
     return 2;
@@ -149,7 +93,11 @@ int main(int argc, char** argv)
         else if (a == "--optimize-opacity") o.optimize_opacity = true;
         else if (a == "--opacity-from") o.opacity_from = std::atoi(next("--opacity-from"));
         else if (a == "--restart-at") o.restart_at = std::atoi(next("--restart-at"));
-        else if (a == "--out-ppm") o.out_ppm = next("--out-ppm");
+        else if (a == "--out-ppm" || a == "--out-image") o.out_image = next("--out-image");
+        else if (a == "--overlay") o.overlay = next("--overlay");
+        else if (a == "--overlay-scale") o.overlay_scale = std::atoi(next("--overlay-scale"));
+        else if (a == "--overlay-stride") o.overlay_stride = std::atoi(next("--overlay-stride"));
+        else if (a == "--convert") { o.convert_in = next("--convert"); o.convert_out = next("--convert"); }
         else if (a == "--load-checkpoint") o.load_ckpt = next("--load-checkpoint");
         else if (a == "--save-checkpoint") o.save_ckpt = next("--save-checkpoint");
         else if (a == "--device") o.device = std::atoi(next("--device"));
@@ -157,18 +105,26 @@ int main(int argc, char** argv)
         else if (a == "--quiet") o.quiet = true;
         else return usage();
     }
-    if (o.image.empty() == (o.syn_w == 0) || o.n_splats < 0 || o.iters < 0 || o.batch < 1) return usage();
+    if (!o.convert_in.empty()) { // file conversion between .s2di / .ppm / .png; touches no GPU
+        s2dio::Image8 im;
+        if (!s2dio::load_image(o.convert_in, &im)) { std::fprintf(stderr, "cannot read %s\n", o.convert_in.c_str()); return 1; }
+        if (!s2dio::save_image(o.convert_out, im)) { std::fprintf(stderr, "cannot write %s\n", o.convert_out.c_str()); return 1; }
+        return 0;
+    }
+    if (o.image.empty() == (o.syn_w == 0) || o.n_splats < 0 || o.iters < 0 || o.batch < 1 || o.overlay_scale < 1) return usage();
 
     // imageRef, main.cpp:253-259
     int W = o.syn_w, H = o.syn_h;
     std::vector<float> imageRef;
     if (!o.image.empty()) {
-        std::vector<uint8_t> rgb;
-        const bool is_ppm = o.image.size() > 4 && o.image.substr(o.image.size() - 4) == ".ppm";
-        if (!(is_ppm ? load_ppm(o.image, &W, &H, &rgb) : load_s2di(o.image, &W, &H, &rgb))) {
-            std::fprintf(stderr, "cannot read %s\n", o.image.c_str());
+        s2dio::Image8 im;
+        if (!s2dio::load_image(o.image, &im)) {
+            std::fprintf(stderr, "cannot read %s (.s2di, binary .ppm and 8-bit non-interlaced .png are supported)\n", o.image.c_str());
             return 1;
         }
+        W = im.w;
+        H = im.h;
+        const std::vector<uint8_t>& rgb = im.rgb;
         imageRef.resize((size_t)W * H * 4);
         for (size_t p = 0; p < (size_t)W * H; p++) { // Image2DRGBA8_to_Image2DRGBA32: byte / 255.0f
             for (int c = 0; c < 3; c++) imageRef[p * 4 + c] = (float)rgb[p * 3 + c] / 255.0f;
@@ -247,11 +203,19 @@ int main(int argc, char** argv)
         if (f) std::fclose(f);
         if (!ok) std::fprintf(stderr, "cannot write %s\n", o.save_ckpt.c_str());
     }
-    if (!o.out_ppm.empty()) {
+    if (!o.out_image.empty() || !o.overlay.empty()) {
         std::vector<float> image0((size_t)W * H * 4);
         CK(s2d_forward(ctx));
         CK(s2d_get_image(ctx, image0.data())); // tex0->upload(image0), main.cpp:794
-        if (!write_ppm(o.out_ppm, W, H, image0)) std::fprintf(stderr, "cannot write %s\n", o.out_ppm.c_str());
+        const s2dio::Image8 im = s2dio::quantise(image0, W, H);
+        if (!o.out_image.empty() && !s2dio::save_image(o.out_image, im)) std::fprintf(stderr, "cannot write %s\n", o.out_image.c_str());
+        if (!o.overlay.empty()) { // the reference's splat visualisation, main.cpp:441-485
+            std::vector<s2d_splat> sp((size_t)o.n_splats);
+            CK(s2d_get_splats(ctx, sp.data()));
+            s2dio::Image8 big = s2dio::upscale(im, o.overlay_scale);
+            s2dio::draw_splat_overlay(&big, sp, o.overlay_scale, o.overlay_stride);
+            if (!s2dio::save_image(o.overlay, big)) std::fprintf(stderr, "cannot write %s\n", o.overlay.c_str());
+        }
     }
     s2d_destroy(ctx);
     return 0;

@@ -626,3 +626,24 @@ def test_against_committed_oracle_golden():
         got = t.get_splats().view(np.float32).reshape(-1, 9).astype(np.float64)
     want = z["splats_after_step"].view(np.float32).reshape(-1, 9).astype(np.float64)
     assert (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max() <= REL
+
+
+def test_cpp_host_png_target_and_overlay(tmp_path):
+    """A PNG target gives the same trace as the raw fixture; --overlay writes the reference's splat debug drawing
+    (main.cpp:441-485) as an image."""
+    import subprocess
+    from PIL import Image
+    exe = S2D._build.build_host_program()
+    png = str(tmp_path / "mini.png")
+    subprocess.run([exe, "--convert", MINI, png], check=True)
+    a = subprocess.run([exe, "--image", png, "--splats", "64", "--iters", "3", "--out-image", str(tmp_path / "o.png"),
+                        "--overlay", str(tmp_path / "ov.png"), "--overlay-scale", "3"], capture_output=True, text=True, check=True)
+    b = subprocess.run([exe, "--image", MINI, "--splats", "64", "--iters", "3"], capture_output=True, text=True, check=True)
+    assert a.stdout == b.stdout
+    o = np.asarray(Image.open(tmp_path / "o.png"))
+    ov = np.asarray(Image.open(tmp_path / "ov.png"))
+    assert o.shape == (213, 268, 3) and ov.shape == (639, 804, 3)
+    up = o.repeat(3, 0).repeat(3, 1)
+    changed = (ov != up).any(axis=2)
+    assert 0.01 < changed.mean() < 0.5            # lines were drawn, the picture is still there
+    assert (ov[changed] == 128).all(axis=1).any() and (ov[changed] == 255).all(axis=1).any()  # grey boxes, white axes
