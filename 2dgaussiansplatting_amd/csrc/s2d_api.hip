@@ -54,8 +54,10 @@ struct s2d_ctx {
     int since_rebin = 0;
     float margin = 0.0f;
     // images
-    float4* d_image0 = nullptr;
-    float4* d_ref = nullptr;
+    void* d_image0 = nullptr;  // RGBA32F, or 4 x fp16 per pixel with S2D_CFG_FP16_IMAGES
+    void* d_ref = nullptr;
+    bool half_images = false;
+    size_t pixel_bytes = sizeof(float4);
     double* d_tile_sqerr = nullptr;
     double* d_sqerr_trace = nullptr;
     int trace_cap = 1 << 16;
@@ -189,7 +191,7 @@ int queue_forward(s2d_ctx* c)
     if (!c->have_target) return fail(c, S2D_E_STATE, "no target image set (s2d_set_target)");
     int rc = prepare_lists(c);
     if (rc != S2D_OK) return rc;
-    S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_wave_masks, c->g,
+    S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->half_images, c->d_wave_masks, c->g,
                                      (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
     c->have_forward = true;
     c->have_backward = false;
@@ -200,8 +202,8 @@ int queue_backward(s2d_ctx* c, bool need_opacity_grad)
 {
     if (!c->have_forward) return fail(c, S2D_E_STATE, "s2d_backward needs s2d_forward on the current parameters");
     const int slot = c->iterations % c->trace_cap;
-    S2D_HIP(c, launch_raster_backward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->d_wave_masks,
-                                      c->d_grads,
+    S2D_HIP(c, launch_raster_backward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->half_images,
+                                      c->d_wave_masks, c->d_grads,
                                       c->d_tile_sqerr, c->g, need_opacity_grad,
                                       (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
     S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->stream));
@@ -294,8 +296,10 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, dev_alloc(&c->d_scan_temp, scan_temp_words((int64_t)n)));
     S2D_HIP(c, dev_alloc(&c->d_total, 4));
     S2D_HIP(c, dev_alloc(&c->d_tile_off, (size_t)g.num_tiles + 1));
-    S2D_HIP(c, dev_alloc(&c->d_image0, px));
-    S2D_HIP(c, dev_alloc(&c->d_ref, px));
+    c->half_images = (cfg->flags & S2D_CFG_FP16_IMAGES) != 0;
+    c->pixel_bytes = c->half_images ? 8 : sizeof(float4);
+    S2D_HIP(c, hipMalloc(&c->d_image0, px * c->pixel_bytes));
+    S2D_HIP(c, hipMalloc(&c->d_ref, px * c->pixel_bytes));
     S2D_HIP(c, dev_alloc(&c->d_tile_sqerr, (size_t)g.num_tiles));
     S2D_HIP(c, dev_alloc(&c->d_sqerr_trace, (size_t)c->trace_cap));
     S2D_HIP(c, dev_alloc(&c->d_status, 1));
@@ -306,8 +310,8 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, hipMemsetAsync(c->d_splats, 0, n * 9 * sizeof(float), c->stream));
     S2D_HIP(c, hipMemsetAsync(c->d_adams, 0, n * 18 * sizeof(float), c->stream));
     S2D_HIP(c, hipMemsetAsync(c->d_grads_own, 0, n * 9 * sizeof(float), c->stream));
-    S2D_HIP(c, hipMemsetAsync(c->d_image0, 0, px * sizeof(float4), c->stream));
-    S2D_HIP(c, hipMemsetAsync(c->d_ref, 0, px * sizeof(float4), c->stream));
+    S2D_HIP(c, hipMemsetAsync(c->d_image0, 0, px * c->pixel_bytes, c->stream));
+    S2D_HIP(c, hipMemsetAsync(c->d_ref, 0, px * c->pixel_bytes, c->stream));
     S2D_HIP(c, hipMemsetAsync(c->d_sqerr_trace, 0, (size_t)c->trace_cap * sizeof(double), c->stream));
     S2D_HIP(c, hipMemsetAsync(c->d_counters, 0, sizeof(PairCounters), c->stream));
     DeviceStatus st0{0, INT_MAX, 0, 0};
@@ -344,9 +348,19 @@ int s2d_set_target(s2d_ctx* c, const float* rgba32f)
 {
     if (!c || !rgba32f) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
-    const size_t bytes = (size_t)c->g.W * c->g.H * sizeof(float4);
-    S2D_HIP(c, hipMemcpyAsync(c->d_ref, rgba32f, bytes, hipMemcpyHostToDevice, c->stream));
-    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    const size_t px = (size_t)c->g.W * c->g.H, bytes = px * sizeof(float4);
+    if (c->half_images) { // floats cross the boundary; the device keeps them as fp16 (round to nearest even)
+        float4* tmp = nullptr;
+        S2D_HIP(c, hipMalloc((void**)&tmp, bytes));
+        hipError_t e = hipMemcpyAsync(tmp, rgba32f, bytes, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = launch_convert_f32_to_f16(tmp, c->d_ref, px, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(tmp);
+        S2D_HIP(c, e);
+    } else {
+        S2D_HIP(c, hipMemcpyAsync(c->d_ref, rgba32f, bytes, hipMemcpyHostToDevice, c->stream));
+        S2D_HIP(c, hipStreamSynchronize(c->stream));
+    }
     c->have_target = true;
     c->have_forward = c->have_backward = false;
     return S2D_OK;
@@ -356,7 +370,7 @@ int s2d_set_target_synthetic(s2d_ctx* c)
 {
     if (!c) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
-    S2D_HIP(c, launch_synthetic_target(c->d_ref, c->g.W, c->g.H, c->stream));
+    S2D_HIP(c, launch_synthetic_target(c->d_ref, c->half_images, c->g.W, c->g.H, c->stream));
     c->have_target = true;
     c->have_forward = c->have_backward = false;
     return S2D_OK;
@@ -433,7 +447,17 @@ int s2d_get_image(s2d_ctx* c, float* rgba32f)
 {
     if (!c || !rgba32f) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
-    const size_t bytes = (size_t)c->g.W * c->g.H * sizeof(float4);
+    const size_t px = (size_t)c->g.W * c->g.H, bytes = px * sizeof(float4);
+    if (c->half_images) {
+        float4* tmp = nullptr;
+        S2D_HIP(c, hipMalloc((void**)&tmp, bytes));
+        hipError_t e = launch_convert_f16_to_f32(c->d_image0, tmp, px, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(rgba32f, tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        (void)hipFree(tmp);
+        S2D_HIP(c, e);
+        return S2D_OK;
+    }
     S2D_HIP(c, hipMemcpyAsync(rgba32f, c->d_image0, bytes, hipMemcpyDeviceToHost, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
     return S2D_OK;

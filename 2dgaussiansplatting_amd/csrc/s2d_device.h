@@ -81,14 +81,13 @@ hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, 
                                uint32_t* tile_off, hipStream_t stream);
 
 // raster (s2d_raster.hip)
-hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
-                                 float4* image0, unsigned long long* wave_masks, Geometry g, PairCounters* counters,
+hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
+                                 bool half_images, unsigned long long* wave_masks, Geometry g, PairCounters* counters,
                                  hipStream_t stream);
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
-                                  const float4* image0, const float4* image_ref,
-                                  const unsigned long long* wave_masks, float* grads,
-                                  double* tile_sqerr, Geometry g, bool need_opacity_grad, PairCounters* counters,
-                                  hipStream_t stream);
+                                  const void* image0, const void* image_ref, bool half_images,
+                                  const unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
+                                  bool need_opacity_grad, PairCounters* counters, hipStream_t stream);
 // Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
 hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, hipStream_t stream);
 
@@ -96,7 +95,10 @@ hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double
 hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream);
 hipError_t launch_adam(float* splats, float* adams, float* grads, int n, int W, int H, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, hipStream_t stream);
-hipError_t launch_synthetic_target(float4* image_ref, int W, int H, hipStream_t stream);
+hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, hipStream_t stream);
+// RGBA32F <-> 4 x fp16 (round to nearest even) for images that cross the boundary as floats
+hipError_t launch_convert_f32_to_f16(const float4* src, void* dst, size_t pixels, hipStream_t stream);
+hipError_t launch_convert_f16_to_f32(const void* src, float4* dst, size_t pixels, hipStream_t stream);
 hipError_t launch_test_sincos(const float* x, int n, float* s, float* c, hipStream_t stream);
 
 } // namespace s2d

@@ -1,4 +1,6 @@
 // s2d_optim.hip -- init(), the Adam step with constraints and finite guard, and small utilities.
+#include <hip/hip_fp16.h>
+
 #include "s2d_device.h"
 
 namespace s2d {
@@ -68,13 +70,43 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
 }
 
 // ref(x,y) = (x/W, 1 - x/W, y/H, 1): main.cpp:261-267's commented generator plus a blue ramp.
-__global__ __launch_bounds__(256) void synthetic_target_kernel(float4* __restrict__ image_ref, int W, int H)
+__device__ __forceinline__ uint2 pack_half4(float4 c)
+{
+    const __half2 a = __floats2half2_rn(c.x, c.y), b = __floats2half2_rn(c.z, c.w);
+    uint2 v;
+    v.x = *reinterpret_cast<const uint32_t*>(&a);
+    v.y = *reinterpret_cast<const uint32_t*>(&b);
+    return v;
+}
+
+template <bool HALF>
+__global__ __launch_bounds__(256) void synthetic_target_kernel(void* __restrict__ image_ref, int W, int H)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
     const int y = blockIdx.y;
     if (x >= W || y >= H) return;
     const float fx = (float)x / (float)W;
-    image_ref[(size_t)y * W + x] = make_float4(fx, 1.0f - fx, (float)y / (float)H, 1.0f);
+    const float4 c = make_float4(fx, 1.0f - fx, (float)y / (float)H, 1.0f);
+    if (HALF) reinterpret_cast<uint2*>(image_ref)[(size_t)y * W + x] = pack_half4(c);
+    else reinterpret_cast<float4*>(image_ref)[(size_t)y * W + x] = c;
+}
+
+__global__ __launch_bounds__(256) void convert_f32_to_f16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst,
+                                                                 size_t pixels)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < pixels) dst[i] = pack_half4(src[i]);
+}
+
+__global__ __launch_bounds__(256) void convert_f16_to_f32_kernel(const uint2* __restrict__ src, float4* __restrict__ dst,
+                                                                 size_t pixels)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= pixels) return;
+    const uint2 v = src[i];
+    const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&v.x));
+    const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&v.y));
+    dst[i] = make_float4(a.x, a.y, b.x, b.y);
 }
 
 __global__ __launch_bounds__(256) void test_sincos_kernel(const float* __restrict__ x, int n, float* __restrict__ s,
@@ -102,9 +134,28 @@ hipError_t launch_adam(float* splats, float* adams, float* grads, int n, int W, 
     return hipGetLastError();
 }
 
-hipError_t launch_synthetic_target(float4* image_ref, int W, int H, hipStream_t stream)
+hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, hipStream_t stream)
 {
-    hipLaunchKernelGGL(synthetic_target_kernel, dim3((W + 255) / 256, H), dim3(256), 0, stream, image_ref, W, H);
+    if (half_images)
+        hipLaunchKernelGGL(synthetic_target_kernel<true>, dim3((W + 255) / 256, H), dim3(256), 0, stream, image_ref, W, H);
+    else
+        hipLaunchKernelGGL(synthetic_target_kernel<false>, dim3((W + 255) / 256, H), dim3(256), 0, stream, image_ref, W, H);
+    return hipGetLastError();
+}
+
+hipError_t launch_convert_f32_to_f16(const float4* src, void* dst, size_t pixels, hipStream_t stream)
+{
+    if (!pixels) return hipSuccess;
+    hipLaunchKernelGGL(convert_f32_to_f16_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream, src,
+                       reinterpret_cast<uint2*>(dst), pixels);
+    return hipGetLastError();
+}
+
+hipError_t launch_convert_f16_to_f32(const void* src, float4* dst, size_t pixels, hipStream_t stream)
+{
+    if (!pixels) return hipSuccess;
+    hipLaunchKernelGGL(convert_f16_to_f32_kernel, dim3((unsigned)((pixels + 255) / 256)), dim3(256), 0, stream,
+                       reinterpret_cast<const uint2*>(src), dst, pixels);
     return hipGetLastError();
 }
 

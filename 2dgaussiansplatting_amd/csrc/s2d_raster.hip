@@ -21,6 +21,8 @@
 // pass makes exactly the forward's per-pixel decisions.  The backward pass then reduces each splat's nine
 // partial gradients over the wave with DPP, over the four waves through per-wave LDS slots (plain stores,
 // fixed order), and issues one global float-atomic burst per (tile, splat) into the N x 9 gradient array.
+#include <hip/hip_fp16.h>
+
 #include "s2d_device.h"
 
 namespace s2d {
@@ -50,6 +52,34 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
     const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, src_lane);
     const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_lane);
     return ((unsigned long long)hi << 32) | lo;
+}
+
+// Framebuffer / target pixel in HBM: RGBA32F (the reference's Image2DRGBA32, 16 B) or, with S2D_CFG_FP16_IMAGES,
+// four IEEE halves (8 B, round-to-nearest-even on store).  Arithmetic is fp32 either way.
+template <bool HALF>
+__device__ __forceinline__ float4 load_pixel(const void* base, size_t i)
+{
+    if (HALF) {
+        const uint2 v = reinterpret_cast<const uint2*>(base)[i];
+        const float2 a = __half22float2(*reinterpret_cast<const __half2*>(&v.x));
+        const float2 b = __half22float2(*reinterpret_cast<const __half2*>(&v.y));
+        return make_float4(a.x, a.y, b.x, b.y);
+    }
+    return reinterpret_cast<const float4*>(base)[i];
+}
+
+template <bool HALF>
+__device__ __forceinline__ void store_pixel(void* base, size_t i, float4 c)
+{
+    if (HALF) {
+        const __half2 a = __floats2half2_rn(c.x, c.y), b = __floats2half2_rn(c.z, c.w);
+        uint2 v;
+        v.x = *reinterpret_cast<const uint32_t*>(&a);
+        v.y = *reinterpret_cast<const uint32_t*>(&b);
+        reinterpret_cast<uint2*>(base)[i] = v;
+    } else {
+        reinterpret_cast<float4*>(base)[i] = c;
+    }
 }
 
 // Pixel of thread tid inside the tile.
@@ -92,11 +122,11 @@ __device__ __forceinline__ void stage_masks(uint32_t* s_mask32, int se, int sub,
 // ---------------------------------------------------------------------------------------------------
 // forward, main.cpp:414-546
 // ---------------------------------------------------------------------------------------------------
-template <bool COUNT>
+template <bool COUNT, bool HALF>
 __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __restrict__ tile_off,
                                                              const uint32_t* __restrict__ list,
                                                              const ProjRec* __restrict__ proj,
-                                                             float4* __restrict__ image0,
+                                                             void* __restrict__ image0,
                                                              unsigned long long* __restrict__ wave_masks, Geometry g,
                                                              PairCounters* __restrict__ counters)
 {
@@ -169,7 +199,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
         }
         if (!__syncthreads_or(alive ? 1 : 0)) break;
     }
-    if (inside) image0[(size_t)y * g.W + x] = make_float4(cr, cg, cb, 1.0f); // .w reset, main.cpp:543-546
+    if (inside) store_pixel<HALF>(image0, (size_t)y * g.W + x, make_float4(cr, cg, cb, 1.0f)); // .w reset, main.cpp:543-546
     if (COUNT) {
         atomicAdd(&counters->fwd_visited, n_vis);
         atomicAdd(&counters->fwd_active, n_act);
@@ -280,12 +310,12 @@ __device__ __forceinline__ float div_by_recip(float num, float den, float r)
 // pixels lie near u = 0).  Only factors that are plain products are regrouped or precomputed per entry
 // (1/sx^3, 1/sy^3, (sx^2-sy^2)/(sx^2 sy^2), 0.5*alpha*(2a vx + (b+c) vy) = alpha*mx): a few ulp per term.
 // ---------------------------------------------------------------------------------------------------
-template <bool COUNT, bool NEED_OP>
+template <bool COUNT, bool NEED_OP, bool HALF>
 __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
                                                               const uint32_t* __restrict__ list,
                                                               const ProjRec* __restrict__ proj,
-                                                              const float4* __restrict__ image0,
-                                                              const float4* __restrict__ image_ref,
+                                                              const void* __restrict__ image0,
+                                                              const void* __restrict__ image_ref,
                                                               const unsigned long long* __restrict__ wave_masks,
                                                               float* __restrict__ grads,
                                                               double* __restrict__ tile_sqerr, Geometry g,
@@ -319,8 +349,8 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
 
     float4 fin = make_float4(0.f, 0.f, 0.f, 0.f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
     if (inside) {
-        fin = image0[(size_t)y * g.W + x];    // finalColor, main.cpp:613
-        ref = image_ref[(size_t)y * g.W + x];
+        fin = load_pixel<HALF>(image0, (size_t)y * g.W + x);    // finalColor, main.cpp:613
+        ref = load_pixel<HALF>(image_ref, (size_t)y * g.W + x);
     }
     const float dLr = fin.x - ref.x, dLg = fin.y - ref.y, dLb = fin.z - ref.z; // dL_dC, main.cpp:616
 
@@ -483,36 +513,40 @@ __global__ __launch_bounds__(1024) void sqerr_finalize_kernel(const double* __re
 
 static inline unsigned raster_grid(int num_tiles) { return (unsigned)(((num_tiles + 7) / 8) * 8); }
 
-hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
-                                 float4* image0, unsigned long long* wave_masks, Geometry g, PairCounters* counters,
+hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
+                                 bool half_images, unsigned long long* wave_masks, Geometry g, PairCounters* counters,
                                  hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
-    if (counters)
-        hipLaunchKernelGGL(raster_forward_kernel<true>, dim3(raster_grid(g.num_tiles)), dim3(256), 0, stream, tile_off,
-                           list, proj, image0, wave_masks, g, counters);
-    else
-        hipLaunchKernelGGL(raster_forward_kernel<false>, dim3(raster_grid(g.num_tiles)), dim3(256), 0, stream,
-                           tile_off, list, proj, image0, wave_masks, g, counters);
+    const dim3 grid(raster_grid(g.num_tiles)), block(256);
+#define S2D_LAUNCH_FWD(C, H) \
+    hipLaunchKernelGGL((raster_forward_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, counters)
+    if (counters) {
+        if (half_images) S2D_LAUNCH_FWD(true, true); else S2D_LAUNCH_FWD(true, false);
+    } else {
+        if (half_images) S2D_LAUNCH_FWD(false, true); else S2D_LAUNCH_FWD(false, false);
+    }
+#undef S2D_LAUNCH_FWD
     return hipGetLastError();
 }
 
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
-                                  const float4* image0, const float4* image_ref,
-                                  const unsigned long long* wave_masks, float* grads,
-                                  double* tile_sqerr, Geometry g, bool need_opacity_grad, PairCounters* counters,
-                                  hipStream_t stream)
+                                  const void* image0, const void* image_ref, bool half_images,
+                                  const unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
+                                  bool need_opacity_grad, PairCounters* counters, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
-#define S2D_LAUNCH_BWD(C, O)                                                                                       \
-    hipLaunchKernelGGL((raster_backward_kernel<C, O>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
+#define S2D_LAUNCH_BWD(C, O, H)                                                                                       \
+    hipLaunchKernelGGL((raster_backward_kernel<C, O, H>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
                        wave_masks, grads, tile_sqerr, g, counters)
+#define S2D_LAUNCH_BWD_H(C, O) do { if (half_images) S2D_LAUNCH_BWD(C, O, true); else S2D_LAUNCH_BWD(C, O, false); } while (0)
     if (counters) {
-        if (need_opacity_grad) S2D_LAUNCH_BWD(true, true); else S2D_LAUNCH_BWD(true, false);
+        if (need_opacity_grad) S2D_LAUNCH_BWD_H(true, true); else S2D_LAUNCH_BWD_H(true, false);
     } else {
-        if (need_opacity_grad) S2D_LAUNCH_BWD(false, true); else S2D_LAUNCH_BWD(false, false);
+        if (need_opacity_grad) S2D_LAUNCH_BWD_H(false, true); else S2D_LAUNCH_BWD_H(false, false);
     }
+#undef S2D_LAUNCH_BWD_H
 #undef S2D_LAUNCH_BWD
     return hipGetLastError();
 }

@@ -78,6 +78,11 @@ typedef enum s2d_status {
 
 /* s2d_config.flags */
 #define S2D_CFG_COUNT_PAIRS 0x1u /* count visited / active pixel-splat pairs in the raster kernels (diagnostic) */
+#define S2D_CFG_FP16_IMAGES 0x2u /* BASELINE configs[4] "fp16 color / fp32 grads": the framebuffer and the target are
+                                  * held in HBM as 4 x fp16 per pixel (round to nearest even); all arithmetic, the
+                                  * gradients and the optimiser stay fp32.  Images still cross this ABI as RGBA32F.
+                                  * Not the reference's arithmetic: results equal the reference run with imageRef and
+                                  * image0 rounded to fp16 (tests/test_gpu_parity.py::test_fp16_images_*). */
 
 typedef struct s2d_config {
     uint32_t struct_size;   /* = sizeof(s2d_config) */

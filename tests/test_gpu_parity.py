@@ -647,3 +647,51 @@ def test_cpp_host_png_target_and_overlay(tmp_path):
     changed = (ov != up).any(axis=2)
     assert 0.01 < changed.mean() < 0.5            # lines were drawn, the picture is still there
     assert (ov[changed] == 128).all(axis=1).any() and (ov[changed] == 255).all(axis=1).any()  # grey boxes, white axes
+
+
+# ---------------------------------------------------------------------------------------------
+# S2D_CFG_FP16_IMAGES (BASELINE configs[4]: "fp16 color / fp32 grads")
+# ---------------------------------------------------------------------------------------------
+def _fp16(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+@pytest.mark.parametrize("n,steps", [(2000, 0), (2000, 6)])
+def test_fp16_images_match_the_oracle_with_rounded_images(n, steps):
+    """With fp16 image storage the GPU must equal the reference loop run on a target rounded to fp16 and with
+    image0 rounded to fp16 between the forward and the backward pass (round to nearest even both sides)."""
+    tgt16 = _fp16(mini_target())
+    o = O.OracleTrainer(tgt16, n)
+    for _ in range(steps):
+        o.forward()
+        o.image0[:] = _fp16(o.image0)
+        o.backward()
+        assert o.adam() == 0
+    with S2D.Trainer(o.W, o.H, n, fp16_images=True, count_pairs=True) as t:
+        t.set_target(mini_target())   # converted on the device
+        t.set_splats(o.splats.view(S2D.SPLAT_DTYPE))
+        t.set_adam(o.adams.view(S2D.ADAM_DTYPE), o.beta1t[0], o.beta2t[0], steps)
+        t.forward()
+        img = t.get_image()
+        want = _fp16(o.forward())
+        assert img.tobytes() == want.tobytes()          # the rounded framebuffer, bit for bit
+        o.image0[:] = want
+        t.backward()
+        grad_check(t.get_grads(), o)
+        assert abs(t.mse() - o.mse()) <= 1e-9 * o.mse()
+
+
+def test_fp16_images_train_like_fp32():
+    tgt = mini_target()
+    res = []
+    for half in (False, True):
+        with S2D.Trainer(268, 213, 1024, fp16_images=half) as t:
+            t.set_target(tgt)
+            t.init()
+            res.append(t.step(60))
+    np.testing.assert_allclose(res[1], res[0], rtol=5e-3)   # fp16 colour costs a few 1e-4 of MSE, no more
+    with S2D.Trainer(2048, 2048, 250_000, fp16_images=True) as t:
+        t.set_target_synthetic()
+        t.init()
+        tr = t.step(5)
+        assert np.isfinite(tr).all() and tr[-1] < tr[0]
