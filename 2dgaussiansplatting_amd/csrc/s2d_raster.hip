@@ -38,13 +38,20 @@ constexpr int kWaveH = 64 / kWaveW;    // pixel rows per wave block
 constexpr int kWavesX = kTile / kWaveW;
 static_assert(kWaveW == 16 || kWaveW == 8, "wave block is 16x4 or 8x8");
 
-// Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of tiles so
-// that neighbouring tiles, which share most of their splat records, hit the same L2.  Speed only.
+// Block -> tile.  Default: dispatch order (blocks are dealt round-robin over the 8 XCDs, which balances the
+// uneven per-tile work best).  -DS2D_XCD_REMAP gives each XCD a contiguous run of tiles instead, so that
+// neighbouring tiles, which share most of their splat records, hit the same L2: measured 1.7 % SLOWER at
+// 4096^2 / 1 M (352 vs 358 it/s) because these kernels are VALU-issue-bound, not L2-bound, and the contiguous
+// runs balance worse.  Kept as a switch for memory-bound configurations.  Speed only, never correctness.
 __device__ __forceinline__ int tile_of_block(int bid, int num_tiles)
 {
+#ifdef S2D_XCD_REMAP
     const int per = (num_tiles + 7) >> 3;
     const int t = (bid & 7) * per + (bid >> 3);
     return t < num_tiles ? t : -1;
+#else
+    return bid < num_tiles ? bid : -1;
+#endif
 }
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src_lane)

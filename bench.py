@@ -191,6 +191,24 @@ def main():
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "kernel_ms": float(bwd_ms.item()), "algorithmic_bytes_per_launch": bwd_bytes},
         }
+        if world == 1:
+            # The path has no dense contraction (no MFMA) and the raster kernels are VALU-issue-bound, so beside the
+            # HBM roofline report the useful fp32 VALU rate: active (pixel, splat) pairs per pass, counted by the
+            # kernels in one extra untimed iteration, x 30 flop (forward, main.cpp:523-533) + 110 flop (backward,
+            # main.cpp:607-709) per pair, against the 157.3 TFLOP/s fp32 vector peak.
+            sp = t.get_splats()
+            with S2D.Trainer(W, H, n, device=device, count_pairs=True) as tc:
+                tc.set_target_synthetic()
+                tc.set_splats(sp)
+                tc.forward()
+                tc.backward()
+                tc.synchronize()
+                cs = tc.stats()
+            flops = 30.0 * cs["fwd_active"] + 110.0 * cs["bwd_active"]
+            out["compute"] = {"unit": "TFLOP/s", "achieved": flops * its / 1e12, "peak": 157.3,
+                              "frac": flops * its / 1e12 / 157.3, "active_pairs_per_pass": cs["bwd_active"],
+                              "lanes_per_executed_wave_entry": cs["bwd_active"] / max(cs["bwd_wave_execs"], 1),
+                              "note": "useful fp32 VALU flops only; kernels are VALU-issue-bound (DESIGN.md section 4)"}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or host_cores()
             out["cpu_baseline"] = cpu_baseline(W, H, n, threads)
