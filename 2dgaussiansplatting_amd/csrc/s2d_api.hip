@@ -1,9 +1,11 @@
 // s2d_api.hip -- the C ABI of include/splat2d.h: context, device memory, iteration sequencing.
 //
 // One iteration (main.cpp:414-809) is queued on the context's stream as
-//   project -> [count scan -> emit -> radix sort -> tile offsets]   (tile lists, when due)
-//   raster_forward -> raster_backward (+ per-tile squared error) -> sqerr_finalize -> adam
-// with no host synchronisation except the 4-byte read of the pair count when the lists are rebuilt.
+//   raster_forward -> raster_backward (+ per-tile squared error) -> sqerr_finalize
+//   -> adam (+ projection of the updated splats and containment check for the next iteration)
+// and, when the tile lists have to be (re)built:  project -> count scan -> emit -> radix sort -> tile offsets.
+// The host never makes the GPU wait: it reads the 4-byte containment flag after launching the forward kernel
+// optimistically, and the 4-byte pair count only when lists are rebuilt.
 #include "../../include/splat2d.h"
 
 #include <algorithm>
@@ -50,6 +52,8 @@ struct s2d_ctx {
     uint64_t pairs = 0;
     uint64_t rebins = 0;
     bool lists_valid = false;
+    bool proj_fresh = false; // d_proj and d_status->rebin_needed describe the CURRENT parameters
+    hipEvent_t ev_flag = nullptr;
     int rebin_interval = 1;
     int since_rebin = 0;
     float margin = 0.0f;
@@ -167,32 +171,48 @@ int rebuild_lists(s2d_ctx* c)
     return S2D_OK;
 }
 
-// Project the splats and make sure the tile lists cover them.
-int prepare_lists(s2d_ctx* c)
+// Forward pass on lists that are known to cover the current parameters.
+int launch_forward(s2d_ctx* c, const int* abort_flag)
 {
-    const bool scheduled = !c->lists_valid || c->rebin_interval <= 1 || c->since_rebin >= c->rebin_interval;
-    if (!scheduled) {
-        // lists are reused: verify on the device that no splat left the rectangle it was binned with
-        S2D_HIP(c, hipMemsetAsync(&c->d_status->rebin_needed, 0, sizeof(int), c->stream));
-        S2D_HIP(c, launch_project(c->d_splats, c->n, c->g, 0.0f, 1, c->d_proj, c->d_rects, c->d_counts, c->d_status,
-                                  c->stream));
-        S2D_HIP(c, hipMemcpyAsync(&c->h_status->rebin_needed, &c->d_status->rebin_needed, sizeof(int),
-                                  hipMemcpyDeviceToHost, c->stream));
-        S2D_HIP(c, hipStreamSynchronize(c->stream));
-        if (!c->h_status->rebin_needed) return S2D_OK;
-    }
-    S2D_HIP(c, launch_project(c->d_splats, c->n, c->g, c->margin, 0, c->d_proj, c->d_rects, c->d_counts, c->d_status,
-                              c->stream));
-    return rebuild_lists(c);
+    S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->half_images, c->d_wave_masks,
+                                     c->g, abort_flag, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr,
+                                     c->stream));
+    return S2D_OK;
 }
 
+// Project the splats, make sure the tile lists cover them, run the forward raster.
+//
+// Steady state (lists re-used): the projection of the current parameters and the containment flag were produced by
+// the Adam kernel of the previous iteration.  The forward kernel is launched OPTIMISTICALLY, right behind an
+// asynchronous copy of that flag: the kernel reads the flag on the device and does nothing if it is set, and the
+// host looks at its copy only after the launch, so the GPU never waits for the host.  If the flag was set the
+// lists are rebuilt and the forward kernel is launched again.
 int queue_forward(s2d_ctx* c)
 {
     if (!c->have_target) return fail(c, S2D_E_STATE, "no target image set (s2d_set_target)");
-    int rc = prepare_lists(c);
-    if (rc != S2D_OK) return rc;
-    S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->half_images, c->d_wave_masks, c->g,
-                                     (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
+    const bool scheduled = !c->lists_valid || c->rebin_interval <= 1 || c->since_rebin >= c->rebin_interval;
+    bool rebuild = scheduled;
+    if (!scheduled) {
+        if (!c->proj_fresh) { // parameters changed without a fused projection: project + check now
+            S2D_HIP(c, hipMemsetAsync(&c->d_status->rebin_needed, 0, sizeof(int), c->stream));
+            S2D_HIP(c, launch_project(c->d_splats, c->n, c->g, 0.0f, 1, c->d_proj, c->d_rects, c->d_counts, c->d_status,
+                                      c->stream));
+            c->proj_fresh = true;
+        }
+        S2D_HIP(c, hipMemcpyAsync(&c->h_status->rebin_needed, &c->d_status->rebin_needed, sizeof(int),
+                                  hipMemcpyDeviceToHost, c->stream));
+        S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
+        if (int rc = launch_forward(c, &c->d_status->rebin_needed)) return rc;
+        S2D_HIP(c, hipEventSynchronize(c->ev_flag)); // the copy, not the kernel
+        rebuild = c->h_status->rebin_needed != 0;
+    }
+    if (rebuild) {
+        S2D_HIP(c, launch_project(c->d_splats, c->n, c->g, c->margin, 0, c->d_proj, c->d_rects, c->d_counts, c->d_status,
+                                  c->stream));
+        if (int rc = rebuild_lists(c)) return rc;
+        c->proj_fresh = true;
+        if (int rc = launch_forward(c, nullptr)) return rc;
+    }
     c->have_forward = true;
     c->have_backward = false;
     return S2D_OK;
@@ -216,8 +236,14 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
 {
     c->beta1t *= kAdamBeta1; // main.cpp:718-719
     c->beta2t *= kAdamBeta2;
-    S2D_HIP(c, launch_adam(c->d_splats, c->d_adams, c->d_grads, c->n, c->g.W, c->g.H, c->beta1t, c->beta2t, c->lr,
-                           (flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0, c->iterations, c->d_status, c->stream));
+    // With re-usable lists the Adam kernel also projects the updated splats and checks them against their binned
+    // rectangles (what the next forward needs), which saves a pass over the parameters per iteration.
+    const bool fuse = c->lists_valid && c->rebin_interval > 1;
+    if (fuse) S2D_HIP(c, hipMemsetAsync(&c->d_status->rebin_needed, 0, sizeof(int), c->stream));
+    S2D_HIP(c, launch_adam(c->d_splats, c->d_adams, c->d_grads, c->n, c->g, c->beta1t, c->beta2t, c->lr,
+                           (flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0, c->iterations, c->d_status,
+                           fuse ? c->d_proj : nullptr, c->d_rects, c->stream));
+    c->proj_fresh = fuse;
     c->iterations++; // main.cpp:809
     c->since_rebin++;
     c->have_forward = false;
@@ -304,6 +330,7 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, dev_alloc(&c->d_sqerr_trace, (size_t)c->trace_cap));
     S2D_HIP(c, dev_alloc(&c->d_status, 1));
     S2D_HIP(c, dev_alloc(&c->d_counters, 1));
+    S2D_HIP(c, hipEventCreateWithFlags(&c->ev_flag, hipEventDisableTiming));
     S2D_HIP(c, hipHostMalloc((void**)&c->h_total, 64, hipHostMallocDefault));
     S2D_HIP(c, hipHostMalloc((void**)&c->h_status, sizeof(DeviceStatus), hipHostMallocDefault));
 
@@ -335,6 +362,7 @@ void s2d_destroy(s2d_ctx* c)
                         c->d_status, c->d_counters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
+        if (c->ev_flag) (void)hipEventDestroy(c->ev_flag);
         if (c->h_total) (void)hipHostFree(c->h_total);
         if (c->h_status) (void)hipHostFree(c->h_status);
         if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -386,6 +414,7 @@ int s2d_init_splats(s2d_ctx* c)
     c->beta2t = 1.0f;
     c->iterations = 0; // main.cpp:281
     c->lists_valid = false;
+    c->proj_fresh = false;
     c->have_forward = c->have_backward = false;
     return S2D_OK;
 }
@@ -397,6 +426,7 @@ int s2d_set_splats(s2d_ctx* c, const s2d_splat* splats)
     S2D_HIP(c, hipMemcpyAsync(c->d_splats, splats, (size_t)c->n * sizeof(s2d_splat), hipMemcpyHostToDevice, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
     c->lists_valid = false;
+    c->proj_fresh = false;
     c->have_forward = c->have_backward = false;
     return S2D_OK;
 }

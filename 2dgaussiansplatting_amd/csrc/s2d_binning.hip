@@ -9,33 +9,6 @@
 
 namespace s2d {
 
-__device__ __forceinline__ float as_f(int v) { return __int_as_float(v); }
-
-// Conservative tile rectangle (local to the slab) of a projected splat, inflated by `margin` pixels.
-// Columns: the exact per-row ranges (row_range) lie within pos_x +- hx up to rounding and the
-// truncation toward zero of negative values; a 1-pixel skirt covers both.
-__device__ __forceinline__ bool tile_rect_of(const Projected& p, const Geometry& g, float margin, TileRect* r)
-{
-    const int m = (int)margin;
-    // rows: [begY, endY] from the reference, clipped to the slab
-    long long y0 = (long long)p.begY - m, y1 = (long long)p.endY + m;
-    if (p.begY == (int)0x80000000u || p.endY == (int)0x80000000u) return false; // NaN / out of range
-    if (y0 < g.row_begin) y0 = g.row_begin;
-    if (y1 > g.row_end - 1) y1 = g.row_end - 1;
-    if (y0 > y1) return false;
-    float xlo = p.pos_x - p.hx - 1.0f - margin;
-    float xhi = p.pos_x + p.hx + 1.0f + margin;
-    if (!(xlo <= xhi)) return false; // NaN
-    if (xhi < 0.0f || xlo > (float)(g.W - 1)) return false;
-    xlo = fmaxf(xlo, 0.0f);
-    xhi = fminf(xhi, (float)(g.W - 1));
-    r->tx0 = (uint16_t)((int)xlo >> 4);
-    r->tx1 = (uint16_t)((int)xhi >> 4);
-    r->ty0 = (uint16_t)(((int)y0 >> 4) - g.trow0);
-    r->ty1 = (uint16_t)(((int)y1 >> 4) - g.trow0);
-    return true;
-}
-
 __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ splats, int n, Geometry g,
                                                       float margin, int mode, ProjRec* __restrict__ proj,
                                                       TileRect* __restrict__ rects, uint32_t* __restrict__ counts,
@@ -48,12 +21,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
     s.pos_x = sp[0]; s.pos_y = sp[1]; s.sx = sp[2]; s.sy = sp[3]; s.rot = sp[4];
     s.col_r = sp[5]; s.col_g = sp[6]; s.col_b = sp[7]; s.opacity = sp[8];
     const Projected p = project(s);
-    ProjRec rec;
-    rec.q0 = make_float4(p.pos_x, p.pos_y, p.a, p.b);
-    rec.q1 = make_float4(p.d, p.col_r, p.col_g, p.col_b);
-    rec.q2 = make_float4(p.opacity, as_f(p.begY), as_f(p.endY), p.cosT);
-    rec.q3 = make_float4(p.sinT, p.sx, p.sy, p.hx);
-    proj[i] = rec;
+    proj[i] = pack_proj(p);
 
     TileRect r;
     r.tx0 = 1; r.tx1 = 0; r.ty0 = 1; r.ty1 = 0;
@@ -64,12 +32,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
         rects[i] = r;
         counts[i] = cnt;
     } else {
-        // the exact rectangle (margin 0) must still lie inside the rectangle the lists were built from
-        if (tile_rect_of(p, g, 0.0f, &r)) {
-            const TileRect b = rects[i];
-            const bool inside = b.tx0 <= b.tx1 && r.tx0 >= b.tx0 && r.tx1 <= b.tx1 && r.ty0 >= b.ty0 && r.ty1 <= b.ty1;
-            if (!inside) atomicOr(&status->rebin_needed, 1);
-        }
+        if (!rect_still_covers(p, g, rects[i])) atomicOr(&status->rebin_needed, 1);
     }
 }
 

@@ -49,6 +49,55 @@ struct DeviceStatus {
     int pad;
 };
 
+#if defined(__HIPCC__)
+__device__ __forceinline__ float as_f(int v) { return __int_as_float(v); }
+
+__device__ __forceinline__ ProjRec pack_proj(const Projected& p)
+{
+    ProjRec rec;
+    rec.q0 = make_float4(p.pos_x, p.pos_y, p.a, p.b);
+    rec.q1 = make_float4(p.d, p.col_r, p.col_g, p.col_b);
+    rec.q2 = make_float4(p.opacity, as_f(p.begY), as_f(p.endY), p.cosT);
+    rec.q3 = make_float4(p.sinT, p.sx, p.sy, p.hx);
+    return rec;
+}
+
+// Conservative tile rectangle (local to the slab) of a projected splat, inflated by `margin` pixels.
+// Columns: the exact per-row ranges (row_range) lie within pos_x +- hx up to rounding and the
+// truncation toward zero of negative values; a 1-pixel skirt covers both.
+__device__ __forceinline__ bool tile_rect_of(const Projected& p, const Geometry& g, float margin, TileRect* r)
+{
+    const int m = (int)margin;
+    // rows: [begY, endY] from the reference, clipped to the slab
+    long long y0 = (long long)p.begY - m, y1 = (long long)p.endY + m;
+    if (p.begY == (int)0x80000000u || p.endY == (int)0x80000000u) return false; // NaN / out of range
+    if (y0 < g.row_begin) y0 = g.row_begin;
+    if (y1 > g.row_end - 1) y1 = g.row_end - 1;
+    if (y0 > y1) return false;
+    float xlo = p.pos_x - p.hx - 1.0f - margin;
+    float xhi = p.pos_x + p.hx + 1.0f + margin;
+    if (!(xlo <= xhi)) return false; // NaN
+    if (xhi < 0.0f || xlo > (float)(g.W - 1)) return false;
+    xlo = fmaxf(xlo, 0.0f);
+    xhi = fminf(xhi, (float)(g.W - 1));
+    r->tx0 = (uint16_t)((int)xlo >> 4);
+    r->tx1 = (uint16_t)((int)xhi >> 4);
+    r->ty0 = (uint16_t)(((int)y0 >> 4) - g.trow0);
+    r->ty1 = (uint16_t)(((int)y1 >> 4) - g.trow0);
+    return true;
+}
+
+// Do the tile lists built from rectangle `binned` still list this splat in every tile it can touch now?
+// (its exact rectangle, margin 0, must lie inside the binned one)
+__device__ __forceinline__ bool rect_still_covers(const Projected& p, const Geometry& g, const TileRect& binned)
+{
+    TileRect r;
+    if (!tile_rect_of(p, g, 0.0f, &r)) return true; // touches nothing
+    return binned.tx0 <= binned.tx1 && r.tx0 >= binned.tx0 && r.tx1 <= binned.tx1 && r.ty0 >= binned.ty0 &&
+           r.ty1 <= binned.ty1;
+}
+#endif
+
 constexpr int kRasterBatch = 64;       // list entries staged in LDS per batch
 constexpr int kSortItemsPerThread = 16;
 constexpr int kSortBlock = 256;
@@ -81,9 +130,11 @@ hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, 
                                uint32_t* tile_off, hipStream_t stream);
 
 // raster (s2d_raster.hip)
+// abort_flag (device, may be null): when it reads non-zero at kernel start the launch does nothing -- the lists it
+// would walk are stale and the host rebuilds them and launches again.
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
-                                 bool half_images, unsigned long long* wave_masks, Geometry g, PairCounters* counters,
-                                 hipStream_t stream);
+                                 bool half_images, unsigned long long* wave_masks, Geometry g, const int* abort_flag,
+                                 PairCounters* counters, hipStream_t stream);
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
                                   const void* image0, const void* image_ref, bool half_images,
                                   const unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
@@ -93,8 +144,11 @@ hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double
 
 // optimiser / init (s2d_optim.hip)
 hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream);
-hipError_t launch_adam(float* splats, float* adams, float* grads, int n, int W, int H, float beta1t, float beta2t,
-                       float lr, int optimize_opacity, int iteration, DeviceStatus* status, hipStream_t stream);
+// proj != nullptr: also project the UPDATED splat for the next iteration and check it against rects[]
+// (what project_kernel mode 1 would do), raising status->rebin_needed.
+hipError_t launch_adam(float* splats, float* adams, float* grads, int n, Geometry g, float beta1t, float beta2t,
+                       float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
+                       const TileRect* rects, hipStream_t stream);
 hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, hipStream_t stream);
 // RGBA32F <-> 4 x fp16 (round to nearest even) for images that cross the boundary as floats
 hipError_t launch_convert_f32_to_f16(const float4* src, void* dst, size_t pixels, hipStream_t stream);

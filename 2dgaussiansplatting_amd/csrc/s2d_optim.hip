@@ -27,11 +27,16 @@ __device__ __forceinline__ bool finite_f32(float x) { return (f32_bits(x) & 0x7f
 // pairs with Adam slot k.  The nine updates are independent, so the reference's update order (color, pos,
 // sx, sy, rot, opacity; main.cpp:723-738) does not matter.  Also re-zeroes the gradient record
 // (main.cpp:550 value-initialises dSplats every iteration).
+// With proj != nullptr the thread goes on to project the updated splat (main.cpp:423-436, 489-491 of the NEXT
+// iteration's forward) and to check it against the rectangle its tile lists were built from, so that the next
+// iteration needs no separate projection pass over the parameters.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, float* __restrict__ adams,
-                                                   float* __restrict__ grads, int n, int W, int H, float beta1t,
+                                                   float* __restrict__ grads, int n, Geometry g, float beta1t,
                                                    float beta2t, float lr, int optimize_opacity, int iteration,
-                                                   DeviceStatus* __restrict__ status)
+                                                   DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
+                                                   const TileRect* __restrict__ rects)
 {
+    const int W = g.W, H = g.H;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     float* sp = splats + (size_t)i * 9;
@@ -66,6 +71,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
     if (!ok) {
         atomicOr(&status->nonfinite, 1);
         atomicMin(&status->first_nonfinite_iter, iteration);
+    }
+    if (proj) {
+        Splat s;
+        s.pos_x = v[0]; s.pos_y = v[1]; s.sx = v[2]; s.sy = v[3]; s.rot = v[4];
+        s.col_r = v[5]; s.col_g = v[6]; s.col_b = v[7]; s.opacity = v[8];
+        const Projected p = project(s);
+        proj[i] = pack_proj(p);
+        if (!rect_still_covers(p, g, rects[i])) atomicOr(&status->rebin_needed, 1);
     }
 }
 
@@ -125,12 +138,13 @@ hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, 
     return hipGetLastError();
 }
 
-hipError_t launch_adam(float* splats, float* adams, float* grads, int n, int W, int H, float beta1t, float beta2t,
-                       float lr, int optimize_opacity, int iteration, DeviceStatus* status, hipStream_t stream)
+hipError_t launch_adam(float* splats, float* adams, float* grads, int n, Geometry g, float beta1t, float beta2t,
+                       float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
+                       const TileRect* rects, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, n, W, H, beta1t,
-                       beta2t, lr, optimize_opacity, iteration, status);
+    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, n, g, beta1t,
+                       beta2t, lr, optimize_opacity, iteration, status, proj, rects);
     return hipGetLastError();
 }
 

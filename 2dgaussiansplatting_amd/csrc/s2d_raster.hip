@@ -135,6 +135,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                                                              const ProjRec* __restrict__ proj,
                                                              void* __restrict__ image0,
                                                              unsigned long long* __restrict__ wave_masks, Geometry g,
+                                                             const int* __restrict__ abort_flag,
                                                              PairCounters* __restrict__ counters)
 {
     __shared__ float4 s_q0[B];
@@ -142,6 +143,10 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
     __shared__ float s_op[B];
     __shared__ unsigned long long s_mask[4 * B]; // [wave][entry]
 
+    // Optimistic launch: the host queues this kernel before it has seen the containment flag the previous Adam
+    // (or projection) kernel produced.  If some splat left its binned rectangle the lists are stale: do nothing;
+    // the host rebuilds them and launches again.  The flag is final before this kernel starts (stream order).
+    if (abort_flag != nullptr && *abort_flag != 0) return;
     const int tile = tile_of_block(blockIdx.x, g.num_tiles);
     if (tile < 0) return;
     const int tx = tile % g.tiles_x;
@@ -521,13 +526,13 @@ __global__ __launch_bounds__(1024) void sqerr_finalize_kernel(const double* __re
 static inline unsigned raster_grid(int num_tiles) { return (unsigned)(((num_tiles + 7) / 8) * 8); }
 
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
-                                 bool half_images, unsigned long long* wave_masks, Geometry g, PairCounters* counters,
-                                 hipStream_t stream)
+                                 bool half_images, unsigned long long* wave_masks, Geometry g, const int* abort_flag,
+                                 PairCounters* counters, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
 #define S2D_LAUNCH_FWD(C, H) \
-    hipLaunchKernelGGL((raster_forward_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, counters)
+    hipLaunchKernelGGL((raster_forward_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, abort_flag, counters)
     if (counters) {
         if (half_images) S2D_LAUNCH_FWD(true, true); else S2D_LAUNCH_FWD(true, false);
     } else {

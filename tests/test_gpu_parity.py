@@ -639,7 +639,11 @@ def test_cpp_host_png_target_and_overlay(tmp_path):
     a = subprocess.run([exe, "--image", png, "--splats", "64", "--iters", "3", "--out-image", str(tmp_path / "o.png"),
                         "--overlay", str(tmp_path / "ov.png"), "--overlay-scale", "3"], capture_output=True, text=True, check=True)
     b = subprocess.run([exe, "--image", MINI, "--splats", "64", "--iters", "3"], capture_output=True, text=True, check=True)
-    assert a.stdout == b.stdout
+    # same pixels in, same trace out (up to run-to-run float-atomic ordering in the gradients)
+    ta = [float(l.split("mse")[1]) for l in a.stdout.strip().splitlines()]
+    tb = [float(l.split("mse")[1]) for l in b.stdout.strip().splitlines()]
+    assert ta[0] == tb[0] and len(ta) == 3
+    np.testing.assert_allclose(ta, tb, rtol=1e-6)
     o = np.asarray(Image.open(tmp_path / "o.png"))
     ov = np.asarray(Image.open(tmp_path / "ov.png"))
     assert o.shape == (213, 268, 3) and ov.shape == (639, 804, 3)
