@@ -51,10 +51,22 @@ def cpu_baseline(W, H, n, threads):
     t0 = time.perf_counter()
     o.step(threads=threads)
     dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
-            "sample": "1 iteration of the same %dx%d / %d-Gaussian workload (oracle/s2d_oracle.c, gcc -O2 "
-                      "-ffp-contract=off, forward+backward over %d row-slab threads, Adam+MSE single thread); "
-                      "%.2f s" % (W, H, n, threads, dt)}
+    out = {"value": 1.0 / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
+           "sample": "1 iteration of the same %dx%d / %d-Gaussian workload (oracle/s2d_oracle.c, gcc -O2 "
+                     "-ffp-contract=off, forward+backward over %d row-slab threads, Adam+MSE single thread); "
+                     "%.2f s" % (W, H, n, threads, dt)}
+    # the reference itself is single-threaded: time one thread on a bounded sample (the top 1/16 of the rows,
+    # forward + backward) and scale by the row count
+    rows = max(16, (H // 16 // 16) * 16)
+    o.init()
+    t0 = time.perf_counter()
+    o.forward(0, rows)
+    o.backward(0, rows)
+    d1 = time.perf_counter() - t0
+    out["single_thread"] = {"value": 1.0 / (d1 * H / rows), "unit": "iterations/s", "cores": 1,
+                            "sample": "forward+backward of rows [0,%d) of the same workload on one thread, %.2f s, "
+                                      "scaled by %d/%d rows" % (rows, d1, H, rows)}
+    return out
 
 
 def main():
@@ -139,7 +151,16 @@ def main():
     t.synchronize()  # raises if a parameter went non-finite
 
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    first = t.stats()["iterations"] - args.steps
+    done = t.stats()["iterations"]
+    first = done - args.steps
+    # PSNR after a fixed 200 iterations: keep training, untimed, up to iteration 200
+    extra = max(0, 200 - done)
+    for _ in range(extra):
+        one_step()
+    torch.cuda.synchronize()
+    sq200 = torch.from_numpy(t.sqerr_trace(max(done + extra - 1, 0), 1)).cuda() if done + extra > 0 else None
+    if dist is not None and sq200 is not None:
+        D.reduce_sqerr(sq200, dist)
     sq = torch.from_numpy(t.sqerr_trace(first, args.steps)).cuda()
     bwd_ms = torch.tensor([sum(a.elapsed_time(b) for a, b in events) / max(args.steps, 1)], dtype=torch.float64, device="cuda")
     if dist is not None:
@@ -166,7 +187,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "train iters/sec (fwd+bwd+Adam)",
+            "metric": "train iters/sec (fwd+bwd+Adam) + PSNR vs ref; 4K img, 1M splats",
             "value": its,
             "unit": "iterations/s",
             "n_gpus": world,
@@ -184,6 +205,8 @@ def main():
                        "rebin_interval": args.rebin_interval},
             "mse_last": mse_last,
             "psnr_db_last": (10.0 * float(np.log10(255.0 ** 2 / mse_last)) if mse_last > 0 else None),
+            "psnr_db_at_iteration": done + extra - 1,
+            "psnr_db": (10.0 * float(np.log10(255.0 ** 2 / (float(sq200[0].item()) / (H * W * 3)))) if sq200 is not None and float(sq200[0].item()) > 0 else None),
             "iterations_total": stats["iterations"],
             "pairs_binned_rank0": stats["pairs_binned"],
             "rebins_rank0": stats["rebins"],
