@@ -46,6 +46,10 @@ struct s2d_ctx {
     uint32_t* d_vals[2] = {nullptr, nullptr};
     uint32_t* d_sort_temp = nullptr;
     unsigned long long* d_wave_masks = nullptr; // 4 x u64 per listed pair: forward -> backward lane masks
+    bool deterministic = false;                 // S2D_CFG_DETERMINISTIC
+    float* d_det_data = nullptr;                // [pair capacity][9] per-(tile, splat) partial gradients
+    uint32_t* d_det_stamp = nullptr;            // [pair capacity]
+    uint32_t det_epoch = 0;                     // stamps written so far (monotone; 0 = never)
     uint64_t pair_capacity = 0;
     uint32_t* d_tile_off = nullptr;
     uint32_t* d_list = nullptr; // == one of d_vals after the sort
@@ -134,8 +138,12 @@ int ensure_pair_capacity(s2d_ctx* c, uint64_t need)
     }
     if (c->d_sort_temp) S2D_HIP(c, hipFree(c->d_sort_temp));
     if (c->d_wave_masks) S2D_HIP(c, hipFree(c->d_wave_masks));
+    if (c->d_det_data) S2D_HIP(c, hipFree(c->d_det_data));
+    if (c->d_det_stamp) S2D_HIP(c, hipFree(c->d_det_stamp));
     c->d_sort_temp = nullptr;
     c->d_wave_masks = nullptr;
+    c->d_det_data = nullptr;
+    c->d_det_stamp = nullptr;
     c->pair_capacity = 0;
     for (int k = 0; k < 2; k++) {
         S2D_HIP(c, dev_alloc(&c->d_keys[k], cap));
@@ -143,6 +151,11 @@ int ensure_pair_capacity(s2d_ctx* c, uint64_t need)
     }
     S2D_HIP(c, dev_alloc(&c->d_sort_temp, sort_temp_words((int64_t)cap)));
     S2D_HIP(c, dev_alloc(&c->d_wave_masks, (size_t)cap * 4));
+    if (c->deterministic) {
+        S2D_HIP(c, dev_alloc(&c->d_det_data, (size_t)cap * 9));
+        S2D_HIP(c, dev_alloc(&c->d_det_stamp, (size_t)cap));
+        S2D_HIP(c, hipMemsetAsync(c->d_det_stamp, 0, (size_t)cap * sizeof(uint32_t), c->stream));
+    }
     c->pair_capacity = cap;
     return S2D_OK;
 }
@@ -222,9 +235,14 @@ int queue_backward(s2d_ctx* c, bool need_opacity_grad)
 {
     if (!c->have_forward) return fail(c, S2D_E_STATE, "s2d_backward needs s2d_forward on the current parameters");
     const int slot = c->iterations % c->trace_cap;
+    DetGather dg{};
+    if (c->deterministic) {
+        c->det_epoch++; // a fresh stamp per backward pass (slots of earlier passes become invalid)
+        dg = DetGather{c->d_rects, c->d_offsets, c->d_counts, c->d_det_data, c->d_det_stamp, c->det_epoch, c->n};
+    }
     S2D_HIP(c, launch_raster_backward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->half_images,
                                       c->d_wave_masks, c->d_grads,
-                                      c->d_tile_sqerr, c->g, need_opacity_grad,
+                                      c->d_tile_sqerr, c->g, need_opacity_grad, c->deterministic ? &dg : nullptr,
                                       (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
     S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->stream));
     c->last_sqerr_slot = slot;
@@ -322,6 +340,7 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, dev_alloc(&c->d_scan_temp, scan_temp_words((int64_t)n)));
     S2D_HIP(c, dev_alloc(&c->d_total, 4));
     S2D_HIP(c, dev_alloc(&c->d_tile_off, (size_t)g.num_tiles + 1));
+    c->deterministic = (cfg->flags & S2D_CFG_DETERMINISTIC) != 0;
     c->half_images = (cfg->flags & S2D_CFG_FP16_IMAGES) != 0;
     c->pixel_bytes = c->half_images ? 8 : sizeof(float4);
     S2D_HIP(c, hipMalloc(&c->d_image0, px * c->pixel_bytes));
@@ -358,7 +377,7 @@ void s2d_destroy(s2d_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         void* ptrs[] = {c->d_splats, c->d_adams, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
-                        c->d_sort_temp, c->d_wave_masks, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_sqerr_trace,
+                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_sqerr_trace,
                         c->d_status, c->d_counters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);

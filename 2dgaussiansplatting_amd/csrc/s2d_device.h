@@ -135,10 +135,23 @@ hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, 
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
                                  bool half_images, unsigned long long* wave_masks, Geometry g, const int* abort_flag,
                                  PairCounters* counters, hipStream_t stream);
+// Deterministic gradient accumulation (S2D_CFG_DETERMINISTIC): instead of float atomics every tile stores its
+// partial gradient of a splat into the slot offsets[splat] + (position of the tile in the splat's emission
+// rectangle), stamped with the iteration; a gather kernel then sums each splat's stamped slots in slot order.
+struct DetGather {
+    const TileRect* rects;
+    const uint32_t* offsets;
+    const uint32_t* counts;
+    float* data;      // [pair capacity][9]
+    uint32_t* stamp;  // [pair capacity]
+    uint32_t now;     // iteration + 1 (never 0: 0 marks a slot that was never written)
+    int n;
+};
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
                                   const void* image0, const void* image_ref, bool half_images,
                                   const unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
-                                  bool need_opacity_grad, PairCounters* counters, hipStream_t stream);
+                                  bool need_opacity_grad, const DetGather* dg, PairCounters* counters,
+                                  hipStream_t stream);
 // Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
 hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, hipStream_t stream);
 

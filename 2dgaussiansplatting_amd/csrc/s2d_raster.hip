@@ -20,7 +20,9 @@
 // (-ffp-contract=off), in both kernels, so the framebuffer is bit-identical to the oracle's and the backward
 // pass makes exactly the forward's per-pixel decisions.  The backward pass then reduces each splat's nine
 // partial gradients over the wave with DPP, over the four waves through per-wave LDS slots (plain stores,
-// fixed order), and issues one global float-atomic burst per (tile, splat) into the N x 9 gradient array.
+// fixed order), and issues one global float-atomic burst per (tile, splat) into the N x 9 gradient array -- or,
+// with S2D_CFG_DETERMINISTIC, stores the partial into the tile's own slot of that splat, and a gather kernel
+// sums each splat's slots in a fixed order (bitwise reproducible gradients).
 #include <hip/hip_fp16.h>
 
 #include "s2d_device.h"
@@ -322,7 +324,16 @@ __device__ __forceinline__ float div_by_recip(float num, float den, float r)
 // pixels lie near u = 0).  Only factors that are plain products are regrouped or precomputed per entry
 // (1/sx^3, 1/sy^3, (sx^2-sy^2)/(sx^2 sy^2), 0.5*alpha*(2a vx + (b+c) vy) = alpha*mx): a few ulp per term.
 // ---------------------------------------------------------------------------------------------------
-template <bool COUNT, bool NEED_OP, bool HALF>
+// Where a tile puts its partial gradient of a splat in deterministic mode.
+struct DetSlots {
+    const TileRect* rects;    // per splat: the rectangle its pairs were emitted from
+    const uint32_t* offsets;  // per splat: first emission slot
+    float* data;              // [pairs][9]
+    uint32_t* stamp;          // [pairs]: iteration + 1 of the last write
+    uint32_t now;             // iteration + 1
+};
+
+template <bool COUNT, bool NEED_OP, bool HALF, bool DET>
 __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
                                                               const uint32_t* __restrict__ list,
                                                               const ProjRec* __restrict__ proj,
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                                                               const unsigned long long* __restrict__ wave_masks,
                                                               float* __restrict__ grads,
                                                               double* __restrict__ tile_sqerr, Geometry g,
-                                                              PairCounters* __restrict__ counters)
+                                                              DetSlots det, PairCounters* __restrict__ counters)
 {
     __shared__ float4 s_q0[B];
     __shared__ float4 s_q1[B];
@@ -477,10 +488,11 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         }
         if (lane == 0) s_touched[w] = touched;
         const int any = __syncthreads_or(alive ? 1 : 0);
-        // one float-atomic burst per (tile, splat): 9 consecutive floats of grads[idx]
+        // one burst per (tile, splat): 9 consecutive floats -- float atomics into grads[idx], or (deterministic
+        // mode) plain stores into this tile's own slot of the splat, summed later in a fixed order
         for (int i = tid; i < cnt * 9; i += 256) {
             const int e = i / 9, k = i - e * 9;
-            if (!NEED_OP && k == 8) continue; // dSplats.opacity left at zero on request
+            if (!NEED_OP && k == 8 && !DET) continue; // dSplats.opacity left at zero on request
             float v = 0.0f;
             bool any_w = false;
 #pragma unroll
@@ -489,7 +501,18 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                     v += reinterpret_cast<const float*>(&s_part[ww][e][0])[k];
                     any_w = true;
                 }
-            if (any_w && v != 0.0f) atomicAdd(grads + (size_t)s_idx[par][e] * 9 + k, v);
+            if (DET) {
+                if (any_w) {
+                    const uint32_t idx = s_idx[par][e];
+                    const TileRect r = det.rects[idx];
+                    const uint32_t slot = det.offsets[idx] + (uint32_t)(ty - g.trow0 - r.ty0) * (uint32_t)(r.tx1 - r.tx0 + 1) +
+                                          (uint32_t)(tx - r.tx0);
+                    det.data[(size_t)slot * 9 + k] = (!NEED_OP && k == 8) ? 0.0f : v;
+                    if (k == 0) det.stamp[slot] = det.now;
+                }
+            } else if (any_w && v != 0.0f) {
+                atomicAdd(grads + (size_t)s_idx[par][e] * 9 + k, v);
+            }
         }
         if (!any) break;
     }
@@ -499,6 +522,29 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         if (tid == 0) atomicAdd(&counters->bwd_staged, n_staged);
         if (lane == 0) atomicAdd(&counters->bwd_wave_execs, n_exec);
     }
+}
+
+// Deterministic mode: gradient of splat i = sum of the partials its tiles stored this iteration, in emission
+// (tile row-major) order -- the same order whatever the dispatch order of the tiles was.
+__global__ __launch_bounds__(256) void gather_grads_kernel(const uint32_t* __restrict__ offsets,
+                                                           const uint32_t* __restrict__ counts, int n,
+                                                           const float* __restrict__ data,
+                                                           const uint32_t* __restrict__ stamp, uint32_t now,
+                                                           float* __restrict__ grads)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const uint32_t o = offsets[i], c = counts[i];
+    for (uint32_t s = o; s < o + c; s++) {
+        if (stamp[s] != now) continue;
+        const float* d = data + (size_t)s * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) acc[k] += d[k];
+    }
+    float* gr = grads + (size_t)i * 9;
+#pragma unroll
+    for (int k = 0; k < 9; k++) gr[k] += acc[k]; // += : the buffer is zero here unless the caller accumulates slabs
 }
 
 // One block, fixed summation order (deterministic MSE trace): 1024 threads, 8 loads in flight per thread.
@@ -545,21 +591,28 @@ hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list,
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
                                   const void* image0, const void* image_ref, bool half_images,
                                   const unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
-                                  bool need_opacity_grad, PairCounters* counters, hipStream_t stream)
+                                  bool need_opacity_grad, const DetGather* dg, PairCounters* counters, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
-#define S2D_LAUNCH_BWD(C, O, H)                                                                                       \
-    hipLaunchKernelGGL((raster_backward_kernel<C, O, H>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
-                       wave_masks, grads, tile_sqerr, g, counters)
-#define S2D_LAUNCH_BWD_H(C, O) do { if (half_images) S2D_LAUNCH_BWD(C, O, true); else S2D_LAUNCH_BWD(C, O, false); } while (0)
+    DetSlots det{nullptr, nullptr, nullptr, nullptr, 0u};
+    if (dg) det = DetSlots{dg->rects, dg->offsets, dg->data, dg->stamp, dg->now};
+#define S2D_LAUNCH_BWD(C, O, H, D)                                                                                       \
+    hipLaunchKernelGGL((raster_backward_kernel<C, O, H, D>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
+                       wave_masks, grads, tile_sqerr, g, det, counters)
+#define S2D_LAUNCH_BWD_D(C, O, H) do { if (dg) S2D_LAUNCH_BWD(C, O, H, true); else S2D_LAUNCH_BWD(C, O, H, false); } while (0)
+#define S2D_LAUNCH_BWD_H(C, O) do { if (half_images) S2D_LAUNCH_BWD_D(C, O, true); else S2D_LAUNCH_BWD_D(C, O, false); } while (0)
     if (counters) {
         if (need_opacity_grad) S2D_LAUNCH_BWD_H(true, true); else S2D_LAUNCH_BWD_H(true, false);
     } else {
         if (need_opacity_grad) S2D_LAUNCH_BWD_H(false, true); else S2D_LAUNCH_BWD_H(false, false);
     }
 #undef S2D_LAUNCH_BWD_H
+#undef S2D_LAUNCH_BWD_D
 #undef S2D_LAUNCH_BWD
+    if (dg && dg->n > 0)
+        hipLaunchKernelGGL(gather_grads_kernel, dim3((dg->n + 255) / 256), dim3(256), 0, stream, dg->offsets, dg->counts,
+                           dg->n, dg->data, dg->stamp, dg->now, grads);
     return hipGetLastError();
 }
 

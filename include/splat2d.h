@@ -70,6 +70,11 @@ typedef enum s2d_status {
 /* s2d_step / s2d_adam_step flags */
 #define S2D_STEP_OPTIMIZE_OPACITY 0x1u /* the "Optimize opacity" checkbox, main.cpp:317, :735-738, :825 */
 
+#define S2D_CFG_DETERMINISTIC 0x4u /* bitwise reproducible gradients: tiles store their per-splat partial sums into
+                                   * private slots and a gather pass adds them in a fixed order, instead of float
+                                   * atomics whose arrival order varies from run to run (the forward pass is
+                                   * deterministic either way).  Costs a few per cent. */
+
 /* s2d_backward flags */
 #define S2D_BWD_SKIP_OPACITY_GRAD 0x1u /* leave dSplats.opacity at zero.  The reference always accumulates it
                                         * (main.cpp:704) but reads it only when "Optimize opacity" is on (main.cpp:735):

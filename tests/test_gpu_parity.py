@@ -699,3 +699,43 @@ def test_fp16_images_train_like_fp32():
         t.init()
         tr = t.step(5)
         assert np.isfinite(tr).all() and tr[-1] < tr[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# S2D_CFG_DETERMINISTIC
+# ---------------------------------------------------------------------------------------------
+def test_deterministic_mode_is_bitwise_reproducible_and_still_in_parity():
+    tgt = mini_target()
+    finals, traces = [], []
+    for interval in (0, 0, 1):   # twice with re-used lists, once rebuilding every iteration: all three identical
+        with S2D.Trainer(268, 213, 2000, deterministic=True, rebin_interval=interval) as t:
+            t.set_target(tgt)
+            t.init()
+            traces.append(t.step(25))
+            finals.append(t.get_splats().tobytes())
+    assert finals[0] == finals[1] == finals[2]
+    assert np.array_equal(traces[0], traces[1]) and np.array_equal(traces[0], traces[2])
+    # parity of the deterministic gradients against the oracle, same bars as the atomic path
+    o, t = make_pair(tgt, 2000, 5, deterministic=True)
+    o.forward()
+    t.forward(); t.backward()
+    g1 = t.get_grads()
+    grad_check(g1, o)
+    t.adam_step()           # re-zeroes the gradient buffer
+    t.set_splats(o.splats.view(S2D.SPLAT_DTYPE))
+    t.forward(); t.backward()
+    assert t.get_grads().tobytes() == g1.tobytes()   # same state, same bits
+    t.close()
+
+
+def test_deterministic_mode_full_size_matches_atomic_mode():
+    res = []
+    for det in (False, True, True):
+        with S2D.Trainer(2048, 2048, 250_000, deterministic=det) as t:
+            t.set_target_synthetic()
+            t.init()
+            t.forward(); t.backward()
+            res.append(t.get_grads().view(np.float32).reshape(-1, 9).astype(np.float64))
+    assert np.array_equal(res[1], res[2])
+    scale = np.abs(res[1]).mean(axis=0)
+    assert (np.abs(res[0] - res[1]) / (np.abs(res[1]) + scale[None, :])).max() < 1e-4
