@@ -91,6 +91,21 @@ __device__ __forceinline__ void store_pixel(void* base, size_t i, float4 c)
     }
 }
 
+// Two fp32 values in an even-aligned register pair: element-wise *, +, - on these compile to v_pk_mul_f32 /
+// v_pk_add_f32, which do both components in the issue slot of one scalar-operand VALU instruction and round
+// each component exactly like the scalar instruction (no contraction: -ffp-contract=off).  The blend and
+// gradient arithmetic below is written on such pairs -- (vx,vy), (mx,my), the (r,g) colour channels, the two
+// covariance dot products -- with every product and sum in the reference's order.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 mk2(float a, float b)
+{
+    f2 r;
+    r.x = a;
+    r.y = b;
+    return r;
+}
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+
 // Pixel of thread tid inside the tile.
 __device__ __forceinline__ void pixel_of_thread(int tid, int* lx, int* ly)
 {
@@ -140,9 +155,9 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                                                              const int* __restrict__ abort_flag,
                                                              PairCounters* __restrict__ counters)
 {
-    __shared__ float4 s_q0[B];
-    __shared__ float4 s_q1[B];
-    __shared__ float s_op[B];
+    __shared__ float4 s_q0[B]; // pos.x, pos.y, a, b
+    __shared__ float4 s_q1[B]; // b, d, col_r, col_g      (b twice: (a,b) and (b,d) are the two columns of inv_cov)
+    __shared__ float2 s_q2[B]; // col_b, opacity
     __shared__ unsigned long long s_mask[4 * B]; // [wave][entry]
 
     // Optimistic launch: the host queues this kernel before it has seen the containment flag the previous Adam
@@ -159,9 +174,10 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
     const int x = tx * kTile + lx;
     const int y = ty * kTile + ly;
     const bool inside = x < g.W && y < g.row_end;
-    const float px = (float)x + 0.5f, py = (float)y + 0.5f; // main.cpp:523
+    const f2 pxy = mk2((float)x + 0.5f, (float)y + 0.5f);   // main.cpp:523
 
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f, T = 1.0f;       // main.cpp:414: (0,0,0,1)
+    f2 crg = mk2(0.0f, 0.0f);                               // main.cpp:414: (0,0,0,1)
+    float cb = 0.0f, T = 1.0f;
     bool alive = inside;
     unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0;
 
@@ -176,8 +192,8 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                         __float_as_int(q2.z), ty * kTile, tx * kTile, g.W, g.row_end);
             if (sub == 0) {
                 s_q0[se] = q0;
-                s_q1[se] = q1;
-                s_op[se] = q2.x;
+                s_q1[se] = make_float4(q0.w, q1.x, q1.y, q1.z);
+                s_q2[se] = make_float2(q1.w, q2.x);
             }
         }
         __syncthreads();
@@ -198,13 +214,15 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                 // the scalar lane mask IS the predicate "pixel visited" (main.cpp:511-514): no per-lane bit test
                 if (__builtin_amdgcn_inverse_ballot_w64(wm) && alive) { // main.cpp:511-521
                     const float4 q0 = s_q0[e], q1 = s_q1[e];
-                    float vx, vy;
-                    const float G = gauss_at(px, py, q0.x, q0.y, q0.z, q0.w, q1.x, &vx, &vy);
-                    const float alpha = G * s_op[e];        // main.cpp:527
-                    cr += T * q1.y * alpha;                  // main.cpp:529-531
-                    cg += T * q1.z * alpha;
-                    cb += T * q1.w * alpha;
-                    T *= (1.0f - alpha);                     // main.cpp:533
+                    const float2 q2 = s_q2[e];
+                    const f2 v = pxy - mk2(q0.x, q0.y);                          // main.cpp:523-524
+                    const f2 m = mk2(q0.z, q0.w) * v.x + mk2(q1.x, q1.y) * v.y;  // inv_cov * v: (a vx + b vy, b vx + d vy)
+                    const f2 vm = v * m;
+                    const float G = gauss_from_d2(vm.x + vm.y);                  // main.cpp:526-527
+                    const float alpha = G * q2.y;
+                    crg += (T * mk2(q1.z, q1.w)) * alpha;                        // main.cpp:529-530: (T*c)*alpha
+                    cb += T * q2.x * alpha;                                      // main.cpp:531
+                    T *= (1.0f - alpha);                                         // main.cpp:533
                     alive = !(T < kMinThroughput);           // main.cpp:520, evaluated for the next splat
                     if (COUNT) n_act++;
                 }
@@ -213,7 +231,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
         }
         if (!__syncthreads_or(alive ? 1 : 0)) break;
     }
-    if (inside) store_pixel<HALF>(image0, (size_t)y * g.W + x, make_float4(cr, cg, cb, 1.0f)); // .w reset, main.cpp:543-546
+    if (inside) store_pixel<HALF>(image0, (size_t)y * g.W + x, make_float4(crg.x, crg.y, cb, 1.0f)); // .w reset, main.cpp:543-546
     if (COUNT) {
         atomicAdd(&counters->fwd_visited, n_vis);
         atomicAdd(&counters->fwd_active, n_act);
@@ -344,10 +362,12 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                                                               double* __restrict__ tile_sqerr, Geometry g,
                                                               DetSlots det, PairCounters* __restrict__ counters)
 {
-    __shared__ float4 s_q0[B];
-    __shared__ float4 s_q1[B];
-    __shared__ float4 s_e0[B]; // cc, 2sc, ss, sc
-    __shared__ float4 s_e1[B]; // 1/sx^3, 1/sy^3, (sx^2-sy^2)/(sx^2 sy^2), opacity
+    __shared__ float4 s_q0[B]; // pos.x, pos.y, a, b
+    __shared__ float4 s_q1[B]; // b, d, col_r, col_g
+    __shared__ float4 s_q2[B]; // col_b, opacity, (sx^2-sy^2)/(sx^2 sy^2), sin*cos
+    __shared__ float4 s_e0[B]; // cc, ss, 2sc, -2sc
+    __shared__ float4 s_e1[B]; // ss, cc, 1/sx^3, 1/sy^3
+    __shared__ float s_e2[B];  // cc - ss
     __shared__ unsigned long long s_mask[4 * B]; // [wave][entry]
     __shared__ uint32_t s_idx[2][B];
     // per-wave partial gradients of the batch: written once per (wave, entry) by lane 63 with plain stores,
@@ -366,7 +386,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     const int x = tx * kTile + lx;
     const int y = ty * kTile + ly;
     const bool inside = x < g.W && y < g.row_end;
-    const float px = (float)x + 0.5f, py = (float)y + 0.5f;
+    const f2 pxy = mk2((float)x + 0.5f, (float)y + 0.5f);
     // after wave_sum8_packed the 8-lane group (lane >> 3) holds the total of record component bitrev3(lane >> 3)
     const int part_slot = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
 
@@ -376,6 +396,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         ref = load_pixel<HALF>(image_ref, (size_t)y * g.W + x);
     }
     const float dLr = fin.x - ref.x, dLg = fin.y - ref.y, dLb = fin.z - ref.z; // dL_dC, main.cpp:616
+    const f2 dLrg = mk2(dLr, dLg), fin_rg = mk2(fin.x, fin.y);
 
     // squared error of this tile (main.cpp:801-802): float per pixel, double across pixels
     {
@@ -388,7 +409,8 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     __syncthreads();
     if (tid == 0) tile_sqerr[tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
 
-    float cr = 0.0f, cg = 0.0f, cb = 0.0f, T = 1.0f; // image1 = (0,0,0,1), main.cpp:549
+    f2 crg = mk2(0.0f, 0.0f);                        // image1 = (0,0,0,1), main.cpp:549
+    float cb = 0.0f, T = 1.0f;
     bool alive = inside;
     unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0;
 
@@ -407,10 +429,13 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                 const float4 q3 = r->q3;
                 const float cosT = q2.w, sinT = q3.x, sx = q3.y, sy = q3.z;
                 const float sx2 = sx * sx, sy2 = sy * sy;
+                const float cc = cosT * cosT, ss = sinT * sinT, sc2 = 2.0f * sinT * cosT;
                 s_q0[se] = q0;
-                s_q1[se] = q1;
-                s_e0[se] = make_float4(cosT * cosT, 2.0f * sinT * cosT, sinT * sinT, sinT * cosT);
-                s_e1[se] = make_float4(1.0f / (sx2 * sx), 1.0f / (sy2 * sy), (sx2 - sy2) / (sx2 * sy * sy), q2.x);
+                s_q1[se] = make_float4(q0.w, q1.x, q1.y, q1.z);
+                s_q2[se] = make_float4(q1.w, q2.x, (sx2 - sy2) / (sx2 * sy * sy), sinT * cosT);
+                s_e0[se] = make_float4(cc, ss, sc2, -sc2);
+                s_e1[se] = make_float4(ss, cc, 1.0f / (sx2 * sx), 1.0f / (sy2 * sy));
+                s_e2[se] = cc - ss;
                 s_idx[par][se] = idx;
             }
         }
@@ -441,39 +466,50 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                 }
                 float g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op = 0.f;
                 {
-                    const float4 q0 = s_q0[e], q1 = s_q1[e];
+                    const float4 q0 = s_q0[e], q1 = s_q1[e], q2 = s_q2[e];
                     const float4 e0 = s_e0[e], e1 = s_e1[e];
                     // ---- the reference's operations, in its order (decides T, alive, the running colour) ----
-                    const float vx = px - q0.x, vy = py - q0.y;                      // main.cpp:607-608
-                    const float mx = q0.z * vx + q0.w * vy;                          // inv_cov * v
-                    const float my = q0.w * vx + q1.x * vy;
-                    const float G = gauss_from_d2(vx * mx + vy * my);                // main.cpp:609-610
-                    const float alpha = act ? G * e1.w : 0.0f;                       // main.cpp:611
-                    const float Tr = T * q1.y, Tg = T * q1.z, Tb = T * q1.w;
-                    cr += Tr * alpha;                                                // main.cpp:623-625
-                    cg += Tg * alpha;
+                    const f2 v = pxy - mk2(q0.x, q0.y);                              // main.cpp:607-608
+                    const f2 m = mk2(q0.z, q0.w) * v.x + mk2(q1.x, q1.y) * v.y;      // inv_cov * v
+                    const f2 vm = v * m;
+                    const float G = gauss_from_d2(vm.x + vm.y);                      // main.cpp:609-610
+                    const float alpha = act ? G * q2.y : 0.0f;                       // main.cpp:611
+                    const f2 Trg = T * mk2(q1.z, q1.w);
+                    const float Tb = T * q2.x;
+                    crg += Trg * alpha;                                              // main.cpp:623-625
                     cb += Tb * alpha;
                     // ---- gradient terms ----
                     const float dC_dc = alpha * T;                                   // main.cpp:618
-                    g_r = dLr * dC_dc;
-                    g_g = dLg * dC_dc;
+                    const f2 g_rg = dLrg * dC_dc;
+                    g_r = g_rg.x;
+                    g_g = g_rg.y;
                     g_b = dLb * dC_dc;
-                    // S / (1 - alpha + 1e-15), main.cpp:627-628: three quotients over one denominator
+                    // S / (1 - alpha + 1e-15), main.cpp:627-628: three quotients over one denominator (div_by_recip)
                     const float den = 1.0f - alpha + 1.0e-15f;
                     float rd = __builtin_amdgcn_rcpf(den);
                     rd = __builtin_fmaf(__builtin_fmaf(-den, rd, 1.0f), rd, rd);
-                    const float dCa_r = Tr - div_by_recip(fin.x - cr, den, rd);      // S = final - colour
-                    const float dCa_g = Tg - div_by_recip(fin.y - cg, den, rd);
+                    const f2 S_rg = fin_rg - crg;                                    // S = final - colour
+                    const f2 nden2 = mk2(-den, -den), rd2 = mk2(rd, rd);
+                    f2 q_rg = S_rg * rd;
+                    q_rg = fma2(fma2(nden2, q_rg, S_rg), rd2, q_rg);
+                    q_rg = fma2(fma2(nden2, q_rg, S_rg), rd2, q_rg);
+                    const f2 dCa_rg = Trg - q_rg;
                     const float dCa_b = Tb - div_by_recip(fin.z - cb, den, rd);
                     // the three channel products may cancel: same products, same order as main.cpp:629-630
-                    const float gs = (dLr * dCa_r + dLg * dCa_g) + dLb * dCa_b;
+                    const f2 pr = dLrg * dCa_rg;
+                    const float gs = (pr.x + pr.y) + dLb * dCa_b;
                     const float ga = gs * alpha;
-                    g_px = ga * mx;                                                  // main.cpp:639, :654
-                    g_py = ga * my;                                                  // main.cpp:640, :655
-                    const float vxx = vx * vx, vxy = vx * vy, vyy = vy * vy;
-                    g_sx = (ga * e1.x) * ((e0.x * vxx + e0.y * vxy) + e0.z * vyy);   // main.cpp:657-659, :677
-                    g_sy = (ga * e1.y) * ((e0.z * vxx - e0.y * vxy) + e0.x * vyy);   // main.cpp:660-662, :678
-                    g_rot = (ga * e1.z) * ((e0.x - e0.z) * vx * vy - e0.w * (vxx - vyy)); // main.cpp:680-685
+                    const f2 g_pos = ga * m;                                         // main.cpp:639-640, :654-655
+                    g_px = g_pos.x;
+                    g_py = g_pos.y;
+                    const f2 vv = v.x * v;                                           // vx*vx, vx*vy
+                    const float vyy = v.y * v.y;
+                    // both covariance dot products at once: (cc,ss)*vxx + (2sc,-2sc)*vxy, then + (ss,cc)*vyy
+                    const f2 dots = (mk2(e0.x, e0.y) * vv.x + mk2(e0.z, e0.w) * vv.y) + mk2(e1.x, e1.y) * vyy;
+                    const f2 g_s = (ga * mk2(e1.z, e1.w)) * dots;                    // main.cpp:657-662, :677-678
+                    g_sx = g_s.x;
+                    g_sy = g_s.y;
+                    g_rot = (ga * q2.z) * (s_e2[e] * v.x * v.y - q2.w * (vv.x - vyy)); // main.cpp:680-685
                     if (NEED_OP) g_op = act ? gs * G : 0.0f;                         // main.cpp:703-704
                     T *= (1.0f - alpha);                                             // main.cpp:707
                     alive = !(T < kMinThroughput);
