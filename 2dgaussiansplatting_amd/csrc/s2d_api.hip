@@ -305,7 +305,7 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     c->device = cfg->device;
     c->lr = cfg->training_rate > 0.0f ? cfg->training_rate : 0.05f; // main.cpp:715
     c->rebin_interval = cfg->rebin_interval > 0 ? cfg->rebin_interval : INT_MAX; // default: rebuild on violation only
-    c->margin = c->rebin_interval > 1 ? (cfg->rebin_margin > 0.0f ? cfg->rebin_margin : 4.0f) : 0.0f;
+    c->margin = c->rebin_interval > 1 ? (cfg->rebin_margin > 0.0f ? cfg->rebin_margin : 2.0f) : 0.0f;
 
     Geometry& g = c->g;
     g.W = cfg->width; g.H = cfg->height;

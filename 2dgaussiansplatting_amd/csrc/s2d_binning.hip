@@ -27,7 +27,10 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
     r.tx0 = 1; r.tx1 = 0; r.ty0 = 1; r.ty1 = 0;
     if (mode == 0) {
         uint32_t cnt = 0;
-        if (tile_rect_of(p, g, margin, &r)) cnt = (uint32_t)(r.tx1 - r.tx0 + 1) * (uint32_t)(r.ty1 - r.ty0 + 1);
+        // Footprints of anisotropic splats change fastest (Adam turns `rot` by up to ~0.05 rad per step, which
+        // moves a bounding box by ~3*|sx - sy|*0.05 px): give them a proportionally wider margin.
+        const float m_eff = margin > 0.0f ? margin + kAnisoMargin * fabsf(p.sx - p.sy) : 0.0f;
+        if (tile_rect_of(p, g, m_eff, &r)) cnt = (uint32_t)(r.tx1 - r.tx0 + 1) * (uint32_t)(r.ty1 - r.ty0 + 1);
         else { r.tx0 = 1; r.tx1 = 0; r.ty0 = 1; r.ty1 = 0; }
         rects[i] = r;
         counts[i] = cnt;

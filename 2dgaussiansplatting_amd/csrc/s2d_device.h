@@ -98,6 +98,7 @@ __device__ __forceinline__ bool rect_still_covers(const Projected& p, const Geom
 }
 #endif
 
+constexpr float kAnisoMargin = 1.0f;   // extra binning margin per pixel of |sx - sy| (list re-use)
 constexpr int kRasterBatch = 64;       // list entries staged in LDS per batch
 constexpr int kSortItemsPerThread = 16;
 constexpr int kSortBlock = 256;

@@ -100,10 +100,10 @@ typedef struct s2d_config {
     float training_rate;    /* 0 -> 0.05f (main.cpp:715) */
     uint32_t flags;         /* S2D_CFG_* */
     /* Tile lists may be re-used across iterations: they are built from tile rectangles inflated by
-     * rebin_margin pixels, and every iteration a device-side check forces a rebuild BEFORE the raster runs if
+     * rebin_margin + |sx - sy| pixels, and every iteration a device-side check forces a rebuild BEFORE the raster runs if
      * any splat's exact rectangle left its binned one, so results do not depend on these two knobs.
      * rebin_interval: 0 -> library default (rebuild only when the check fires); 1 -> rebuild every iteration;
-     * K > 1 -> additionally rebuild at least every K iterations.  rebin_margin: 0 -> default (4 pixels). */
+     * K > 1 -> additionally rebuild at least every K iterations.  rebin_margin: 0 -> default (2 pixels). */
     int32_t rebin_interval;
     float rebin_margin;
     void* stream;           /* hipStream_t to queue work on; NULL -> the context creates its own */
