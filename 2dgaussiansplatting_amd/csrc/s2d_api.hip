@@ -224,6 +224,8 @@ int queue_forward(s2d_ctx* c)
                                   c->stream));
         if (int rc = rebuild_lists(c)) return rc;
         c->proj_fresh = true;
+        // the new lists cover the current parameters: the flag that asked for them is spent
+        S2D_HIP(c, hipMemsetAsync(&c->d_status->rebin_needed, 0, sizeof(int), c->stream));
         if (int rc = launch_forward(c, nullptr)) return rc;
     }
     c->have_forward = true;

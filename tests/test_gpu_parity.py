@@ -739,3 +739,19 @@ def test_deterministic_mode_full_size_matches_atomic_mode():
     assert np.array_equal(res[1], res[2])
     scale = np.abs(res[1]).mean(axis=0)
     assert (np.abs(res[0] - res[1]) / (np.abs(res[1]) + scale[None, :])).max() < 1e-4
+
+
+def test_repeated_forward_does_not_rebuild_lists_again():
+    tgt = mini_target()
+    with S2D.Trainer(268, 213, 2000, training_rate=4.0) as t:   # lr 4: every step pushes splats out of their rectangles
+        t.set_target(tgt)
+        t.init()
+        for _ in range(3):
+            t.forward(); t.backward(); t.adam_step()
+        t.forward()
+        r1 = t.stats()["rebins"]
+        img1 = t.get_image()
+        t.forward()
+        t.forward()
+        assert t.stats()["rebins"] == r1
+        assert t.get_image().tobytes() == img1.tobytes()
