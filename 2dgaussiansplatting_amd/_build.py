@@ -56,7 +56,7 @@ def build_host_program(force=False, verbose=False):
     src = os.path.join(HOST_DIR, "splat2d_train.cpp")
     if not os.path.exists(src):
         return None
-    deps = [src, os.path.join(HOST_DIR, "image_io.h"), os.path.join(HOST_DIR, "overlay.h"),
+    deps = [src, os.path.join(HOST_DIR, "image_io.h"), os.path.join(HOST_DIR, "overlay.h"), os.path.join(HOST_DIR, "jpeg_decode.h"),
             os.path.join(ROOT, "include", "splat2d.h"), LIB_PATH]
     if force or _stale(TRAIN_BIN, deps):
         cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", TRAIN_BIN, src,

@@ -1,7 +1,8 @@
 // image_io.h -- image files for the host program: the reference loads its target through prlib/stb_image
 // (main.cpp:253-259) and shows image0 in a window (:794, :839-840); headless, that becomes file I/O.
 // Readers return tightly packed RGB8.  Formats: .s2di (the repo's raw fixtures), binary PPM (P6), PNG
-// (8-bit grey / RGB / palette / with or without alpha, non-interlaced; inflate/deflate by zlib).  Host-side
+// (8-bit grey / RGB / palette / with or without alpha, non-interlaced; inflate/deflate by zlib), JPEG (read only,
+// jpeg_decode.h).  Host-side
 // C++ only: nothing here is on the training path.
 #pragma once
 
@@ -13,6 +14,8 @@
 #include <cstring>
 #include <string>
 #include <vector>
+
+#include "jpeg_decode.h"
 
 namespace s2dio {
 
@@ -150,6 +153,7 @@ inline bool load_image(const std::string& path, Image8* im)
     std::vector<uint8_t> d;
     if (!read_file(path, &d)) return false;
     if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') return load_png(d, im);
+    if (d.size() >= 4 && d[0] == 0xFF && d[1] == 0xD8) return load_jpeg(d, &im->w, &im->h, &im->rgb);
     if (d.size() >= 4 && !std::memcmp(d.data(), "S2DI", 4)) return load_s2di(d, im);
     if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') return load_ppm(d, im);
     return false;

@@ -55,10 +55,10 @@ struct CkptHeader {
 int usage()
 {
     std::fprintf(stderr,
-                 "usage: splat2d_train (--image file.s2di|.ppm|.png | --synthetic WxH) [--splats N] [--iters K] [--batch B]\n"
+                 "usage: splat2d_train (--image file.s2di|.ppm|.png|.jpg | --synthetic WxH) [--splats N] [--iters K] [--batch B]\n"
                  "                     [--optimize-opacity [--opacity-from IT]] [--restart-at IT] [--out-image file.png|.ppm]\n"
                  "                     [--overlay file [--overlay-scale S] [--overlay-stride K]]\n"
-                 "       splat2d_train --convert in.(s2di|ppm|png) out.(s2di|ppm|png)\n"
+                 "       splat2d_train --convert in.(s2di|ppm|png|jpg) out.(s2di|ppm|png)\n"
                  "                     [--load-checkpoint file] [--save-checkpoint file]\n"
                  "                     [--device D] [--rebin-interval R] [--quiet]\n");
     return 2;
@@ -119,7 +119,7 @@ int main(int argc, char** argv)
     if (!o.image.empty()) {
         s2dio::Image8 im;
         if (!s2dio::load_image(o.image, &im)) {
-            std::fprintf(stderr, "cannot read %s (.s2di, binary .ppm and 8-bit non-interlaced .png are supported)\n", o.image.c_str());
+            std::fprintf(stderr, "cannot read %s (.s2di, binary .ppm, 8-bit non-interlaced .png and Huffman .jpg are supported)\n", o.image.c_str());
             return 1;
         }
         W = im.w;

@@ -60,3 +60,51 @@ def test_bad_files_are_rejected(exe, tmp_path):
     open(tmp_path / "corrupt.png", "wb").write(corrupt)
     conv(exe, tmp_path / "corrupt.png", tmp_path / "y.ppm", ok=False)
     conv(exe, tmp_path / "missing.ppm", tmp_path / "z.ppm", ok=False)
+
+
+# ---------------------------------------------------------------------------------------------
+# JPEG (2dgaussiansplatting_amd/host/jpeg_decode.h): restated IJG islow IDCT / fancy upsampling / YCC->RGB
+# ---------------------------------------------------------------------------------------------
+def _jpeg_cases():
+    for sub in (0, 1, 2):                       # 4:4:4, 4:2:2, 4:2:0
+        for prog in (False, True):
+            yield dict(quality=85, subsampling=sub, progressive=prog)
+    yield dict(quality=30, subsampling=2, progressive=True, optimize=True)
+    yield dict(quality=98, subsampling=0)
+    yield dict(quality=75, subsampling=2, restart_marker_blocks=5)
+    yield dict(quality=75, subsampling=1, progressive=True, restart_marker_rows=1)
+
+
+@pytest.mark.parametrize("kw", list(_jpeg_cases()), ids=lambda k: "-".join("%s%s" % (a[:4], b) for a, b in k.items()))
+@pytest.mark.parametrize("crop", [(268, 213), (267, 211), (17, 9), (8, 8), (1, 1)])
+def test_jpeg_decoder_matches_pil_bit_for_bit(exe, tmp_path, kw, crop):
+    rgb = O.load_s2di(MINI)[:crop[1], :crop[0]]
+    src = tmp_path / "in.jpg"
+    try:
+        Image.fromarray(rgb).save(src, format="JPEG", **kw)
+    except TypeError:
+        pytest.skip("this Pillow cannot write restart markers")
+    conv(exe, src, tmp_path / "out.s2di")
+    got = O.load_s2di(str(tmp_path / "out.s2di"))
+    want = np.asarray(Image.open(src).convert("RGB"))
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), "max abs diff %d" % np.abs(got.astype(int) - want.astype(int)).max()
+
+
+def test_jpeg_greyscale_and_corrupt(exe, tmp_path):
+    rgb = O.load_s2di(MINI)
+    Image.fromarray(rgb).convert("L").save(tmp_path / "g.jpg", quality=80)
+    conv(exe, tmp_path / "g.jpg", tmp_path / "g.s2di")
+    assert np.array_equal(O.load_s2di(str(tmp_path / "g.s2di")), np.asarray(Image.open(tmp_path / "g.jpg").convert("RGB")))
+    data = open(tmp_path / "g.jpg", "rb").read()
+    open(tmp_path / "trunc.jpg", "wb").write(data[:200])
+    conv(exe, tmp_path / "trunc.jpg", tmp_path / "t.ppm", ok=False)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/bin/squirrel_cls_mini.jpg"), reason="reference tree not present (GPU box)")
+def test_decoding_the_reference_jpegs_reproduces_the_committed_fixtures(exe, tmp_path):
+    """The host tool reads the reference's own inputs (main.cpp:257) and lands on exactly the pixels of
+    tests/golden/*.s2di (decoded once with PIL), i.e. on the sha256 prefixes recorded in SURVEY.md section 8c."""
+    for jpg, fixture in (("squirrel_cls_mini.jpg", "squirrel_cls_mini_268x213.s2di"), ("squirrel_cls.jpg", "squirrel_cls_535x426.s2di")):
+        conv(exe, "/root/reference/bin/" + jpg, tmp_path / "o.s2di")
+        assert open(tmp_path / "o.s2di", "rb").read() == open(os.path.join(O.GOLDEN, fixture), "rb").read()
