@@ -81,7 +81,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 3])
 def test_gloo_row_slabs_match_single_process(tmp_path, world):
     steps, n = 4, 600
     out = str(tmp_path / "res")
