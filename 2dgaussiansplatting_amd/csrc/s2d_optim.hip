@@ -73,6 +73,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
         atomicMin(&status->first_nonfinite_iter, iteration);
     }
     if (proj) {
+        // A rank that owns a row slab only ever reads the records of splats that can touch its rows.  A splat whose
+        // 3-sigma circle (plus the 1-pixel skirt) stays clear of the slab has an empty exact rectangle, which every
+        // binned rectangle covers: skip its projection (7/8 of the splats at 8 ranks).  NaNs fall through.
+        const float reach = 3.0f * fmaxf(v[2], v[3]) + 2.0f;
+        if (v[1] + reach < (float)g.row_begin || v[1] - reach > (float)g.row_end) return;
         Splat s;
         s.pos_x = v[0]; s.pos_y = v[1]; s.sx = v[2]; s.sy = v[3]; s.rot = v[4];
         s.col_r = v[5]; s.col_g = v[6]; s.col_b = v[7]; s.opacity = v[8];
