@@ -51,7 +51,15 @@ def cpu_baseline(W, H, n, threads):
     t0 = time.perf_counter()
     o.step(threads=threads)
     dt = time.perf_counter() - t0
-    out = {"value": 1.0 / dt, "unit": "iterations/s", "cores": threads, "kind": "port",
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    out = {"value": 1.0 / dt, "unit": "iterations/s", "cores": threads, "kind": "port", "cpu_model": model,
            "sample": "1 iteration of the same %dx%d / %d-Gaussian workload (oracle/s2d_oracle.c, gcc -O2 "
                      "-ffp-contract=off, forward+backward over %d row-slab threads, Adam+MSE single thread); "
                      "%.2f s" % (W, H, n, threads, dt)}

@@ -37,7 +37,7 @@ if rank == 0:
         refp = s.get_splats().view(np.float32).reshape(-1)
     same = all(p.numpy().tobytes() == allp[0].numpy().tobytes() for p in allp)
     print("replicas identical:", same)
-    print("mse 2-rank :", " ".join("%.4f" % v for v in sq))
+    print("mse %d-rank :" % world, " ".join("%.4f" % v for v in sq))
     print("mse 1-rank :", " ".join("%.4f" % v for v in ref))
     print("max rel mse diff %.2e ; max abs param diff %.2e" % (np.max(np.abs(sq - ref) / ref), np.max(np.abs(allp[0].numpy() - refp))))
     assert same and np.max(np.abs(sq - ref) / ref) < 1e-4
