@@ -21,7 +21,7 @@ HIP_HEADERS = ["s2d_device.h", "s2d_math.h"]
 
 # -ffp-contract=off: the kernels keep the reference's evaluation order (no FMA contraction) wherever a
 # discrete decision or the framebuffer depends on it; fp32 divide/sqrt stay correctly rounded (hipcc default).
-HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared",
+HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
                "-Wall", "-Wno-unused-function"]
 
 

@@ -91,12 +91,40 @@ __device__ __forceinline__ void store_pixel(void* base, size_t i, float4 c)
     }
 }
 
-// Two fp32 values in an even-aligned register pair: element-wise *, +, - on these compile to v_pk_mul_f32 /
-// v_pk_add_f32, which do both components in the issue slot of one scalar-operand VALU instruction and round
-// each component exactly like the scalar instruction (no contraction: -ffp-contract=off).  The blend and
-// gradient arithmetic below is written on such pairs -- (vx,vy), (mx,my), the (r,g) colour channels, the two
-// covariance dot products -- with every product and sum in the reference's order.
+// A pair of fp32 values -- (vx,vy), (mx,my), the (r,g) colour channels, the two covariance dot products.  The blend
+// and gradient arithmetic below is written on such pairs with every product and sum in the reference's order.
+// Default: a plain struct whose operators are two scalar VALU instructions each.  Measured on MI355X
+// (tools/microbench/valu_rates.hip, profiles/r01/valu_rates.txt): a v_pk_{mul,add,fma}_f32 occupies a SIMD four
+// times as long as a v_{mul,add,fma}_f32, i.e. packed fp32 runs at HALF the per-component rate of scalar fp32 on
+// gfx950, so the pairs are deliberately NOT register-pair vectors and the build passes -fno-slp-vectorize to stop
+// LLVM from re-packing them.  -DS2D_PACKED_F32=1 selects the ext_vector_type form (v_pk_*_f32) for comparison;
+// both round each component exactly like the scalar instruction (no contraction: -ffp-contract=off).
+#ifndef S2D_PACKED_F32
+#define S2D_PACKED_F32 0
+#endif
+#if S2D_PACKED_F32
 typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct f2 {
+    float x, y;
+};
+__device__ __forceinline__ f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f2 operator*(f2 a, float b) { return f2{a.x * b, a.y * b}; }
+__device__ __forceinline__ f2 operator*(float a, f2 b) { return f2{a * b.x, a * b.y}; }
+__device__ __forceinline__ f2 operator+(f2 a, float b) { return f2{a.x + b, a.y + b}; }
+__device__ __forceinline__ f2 operator+(float a, f2 b) { return f2{a + b.x, a + b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a, float b) { return f2{a.x - b, a.y - b}; }
+__device__ __forceinline__ f2 operator-(float a, f2 b) { return f2{a - b.x, a - b.y}; }
+__device__ __forceinline__ f2 operator-(f2 a) { return f2{-a.x, -a.y}; }
+__device__ __forceinline__ f2& operator+=(f2& a, f2 b) { a = a + b; return a; }
+__device__ __forceinline__ f2& operator-=(f2& a, f2 b) { a = a - b; return a; }
+__device__ __forceinline__ f2& operator*=(f2& a, f2 b) { a = a * b; return a; }
+__device__ __forceinline__ f2& operator*=(f2& a, float b) { a = a * b; return a; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return f2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
+#endif
 __device__ __forceinline__ f2 mk2(float a, float b)
 {
     f2 r;
@@ -104,7 +132,6 @@ __device__ __forceinline__ f2 mk2(float a, float b)
     r.y = b;
     return r;
 }
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // Pixel of thread tid inside the tile.
 __device__ __forceinline__ void pixel_of_thread(int tid, int* lx, int* ly)
@@ -560,6 +587,11 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     }
 }
 
+#ifndef S2D_PPL
+#define S2D_PPL 1 // pixels per lane: 1 = raster_*_kernel above, 2 = raster_*2_kernel (s2d_raster2.inc)
+#endif
+#include "s2d_raster2.inc"
+
 // Deterministic mode: gradient of splat i = sum of the partials its tiles stored this iteration, in emission
 // (tile row-major) order -- the same order whatever the dispatch order of the tiles was.
 __global__ __launch_bounds__(256) void gather_grads_kernel(const uint32_t* __restrict__ offsets,
@@ -612,9 +644,15 @@ hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list,
                                  PairCounters* counters, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
+#if S2D_PPL == 2
+    const dim3 grid(raster_grid(g.num_tiles)), block(kBlock2);
+#define S2D_LAUNCH_FWD(C, H) \
+    hipLaunchKernelGGL((raster_forward2_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, abort_flag, counters)
+#else
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
 #define S2D_LAUNCH_FWD(C, H) \
     hipLaunchKernelGGL((raster_forward_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, abort_flag, counters)
+#endif
     if (counters) {
         if (half_images) S2D_LAUNCH_FWD(true, true); else S2D_LAUNCH_FWD(true, false);
     } else {
@@ -630,12 +668,19 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
                                   bool need_opacity_grad, const DetGather* dg, PairCounters* counters, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
-    const dim3 grid(raster_grid(g.num_tiles)), block(256);
     DetSlots det{nullptr, nullptr, nullptr, nullptr, 0u};
     if (dg) det = DetSlots{dg->rects, dg->offsets, dg->data, dg->stamp, dg->now};
+#if S2D_PPL == 2
+    const dim3 grid(raster_grid(g.num_tiles)), block(kBlock2);
+#define S2D_LAUNCH_BWD(C, O, H, D)                                                                                       \
+    hipLaunchKernelGGL((raster_backward2_kernel<C, O, H, D>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
+                       wave_masks, grads, tile_sqerr, g, det, counters)
+#else
+    const dim3 grid(raster_grid(g.num_tiles)), block(256);
 #define S2D_LAUNCH_BWD(C, O, H, D)                                                                                       \
     hipLaunchKernelGGL((raster_backward_kernel<C, O, H, D>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
                        wave_masks, grads, tile_sqerr, g, det, counters)
+#endif
 #define S2D_LAUNCH_BWD_D(C, O, H) do { if (dg) S2D_LAUNCH_BWD(C, O, H, true); else S2D_LAUNCH_BWD(C, O, H, false); } while (0)
 #define S2D_LAUNCH_BWD_H(C, O) do { if (half_images) S2D_LAUNCH_BWD_D(C, O, true); else S2D_LAUNCH_BWD_D(C, O, false); } while (0)
     if (counters) {
