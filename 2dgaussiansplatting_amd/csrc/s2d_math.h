@@ -142,6 +142,19 @@ S2D_HD float gauss_from_d2(float d2)
     return x;
 }
 
+// gauss_from_d2 with the cut-off handed back as a predicate instead of applied: returns x^8 (x = 1 - d2/16) and
+// *nonzero = !(x < cut-off).  gauss_from_d2(d2) == (*nonzero ? result : 0) bit for bit, NaN included; the raster
+// kernels AND the predicate into the lane mask that selects alpha, saving one select per blended pixel.
+S2D_HD float gauss_pow8(float d2, bool* nonzero)
+{
+    float x = ::fmaf(d2, -0.0625f, 1.0f);
+    *nonzero = !(x < 0.00001814586175896693021059036255f);
+    x *= x;
+    x *= x;
+    x *= x;
+    return x;
+}
+
 // C float -> int conversion as the reference's x86-64 build performs it (cvttss2si): truncation
 // toward zero, and the "integer indefinite" value INT_MIN for NaN / out-of-range inputs.
 S2D_HD int cvt_trunc(float f)

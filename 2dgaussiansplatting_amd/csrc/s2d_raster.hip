@@ -182,9 +182,10 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                                                              const int* __restrict__ abort_flag,
                                                              PairCounters* __restrict__ counters)
 {
-    __shared__ float4 s_q0[B]; // pos.x, pos.y, a, b
-    __shared__ float4 s_q1[B]; // b, d, col_r, col_g      (b twice: (a,b) and (b,d) are the two columns of inv_cov)
-    __shared__ float2 s_q2[B]; // col_b, opacity
+    // per-entry record, three 16-B rows at one LDS address (one address register for the blend loop's reads):
+    //   [0] pos.x, pos.y, a, b   [1] b, d, col_r, col_g   [2] col_b, opacity, -, -
+    // (b twice: (a,b) and (b,d) are the two columns of inv_cov)
+    __shared__ float4 s_rec[B][3];
     __shared__ unsigned long long s_mask[4 * B]; // [wave][entry]
 
     // Optimistic launch: the host queues this kernel before it has seen the containment flag the previous Adam
@@ -205,7 +206,10 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
 
     f2 crg = mk2(0.0f, 0.0f);                               // main.cpp:414: (0,0,0,1)
     float cb = 0.0f, T = 1.0f;
-    bool alive = inside;
+    // Pixels still above the throughput cut-off (main.cpp:520), as ONE wave-uniform 64-bit mask in scalar registers.
+    // (A per-lane bool here costs ~15 scalar instructions per blended entry to merge with exec, and the CU's
+    // single scalar unit -- not the SIMDs -- then bounds the loop; measured, profiles/r01/valu_rates.txt.)
+    unsigned long long alive_mask = __ballot(inside);
     unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0;
 
     const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
@@ -218,16 +222,15 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
             stage_masks(reinterpret_cast<uint32_t*>(s_mask), se, sub, q0, q1, __float_as_int(q2.y),
                         __float_as_int(q2.z), ty * kTile, tx * kTile, g.W, g.row_end);
             if (sub == 0) {
-                s_q0[se] = q0;
-                s_q1[se] = make_float4(q0.w, q1.x, q1.y, q1.z);
-                s_q2[se] = make_float2(q1.w, q2.x);
+                s_rec[se][0] = q0;
+                s_rec[se][1] = make_float4(q0.w, q1.x, q1.y, q1.z);
+                s_rec[se][2] = make_float4(q1.w, q2.x, 0.0f, 0.0f);
             }
         }
         __syncthreads();
         // keep the lane masks for the backward pass, which walks exactly these batches (32 B per staged pair)
         if (se < cnt) wave_masks[(size_t)(base + se) * 4 + sub] = s_mask[sub * B + se];
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
-        unsigned long long alive_mask = __ballot(alive);
         if (alive_mask != 0ull || COUNT) {
             const unsigned long long my_mask = (lane < cnt) ? s_mask[w * B + lane] : 0ull;
             unsigned long long cand = __ballot(my_mask != 0ull); // entries that touch this wave's block at all
@@ -236,27 +239,27 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                 cand &= cand - 1ull;
                 const unsigned long long wm = readlane_u64(my_mask, e);
                 if (COUNT) n_vis += (wm >> lane) & 1ull;
-                if ((wm & alive_mask) == 0ull) continue;
+                const unsigned long long act = wm & alive_mask; // visited (main.cpp:511-514) and not cut off (:520)
+                if (act == 0ull) continue;
                 if (COUNT) n_exec += (lane == 0);
-                // the scalar lane mask IS the predicate "pixel visited" (main.cpp:511-514): no per-lane bit test
-                if (__builtin_amdgcn_inverse_ballot_w64(wm) && alive) { // main.cpp:511-521
-                    const float4 q0 = s_q0[e], q1 = s_q1[e];
-                    const float2 q2 = s_q2[e];
-                    const f2 v = pxy - mk2(q0.x, q0.y);                          // main.cpp:523-524
-                    const f2 m = mk2(q0.z, q0.w) * v.x + mk2(q1.x, q1.y) * v.y;  // inv_cov * v: (a vx + b vy, b vx + d vy)
-                    const f2 vm = v * m;
-                    const float G = gauss_from_d2(vm.x + vm.y);                  // main.cpp:526-527
-                    const float alpha = G * q2.y;
-                    crg += (T * mk2(q1.z, q1.w)) * alpha;                        // main.cpp:529-530: (T*c)*alpha
-                    cb += T * q2.x * alpha;                                      // main.cpp:531
-                    T *= (1.0f - alpha);                                         // main.cpp:533
-                    alive = !(T < kMinThroughput);           // main.cpp:520, evaluated for the next splat
-                    if (COUNT) n_act++;
-                }
-                alive_mask = __ballot(alive);
+                // Branch-free body: lanes outside `act` run the same instructions with alpha forced to 0, which
+                // makes c += (T*c)*0 and T *= 1 exact no-ops.  The scalar mask itself is the select predicate.
+                const float4 q0 = s_rec[e][0], q1 = s_rec[e][1], q2 = s_rec[e][2];
+                const f2 v = pxy - mk2(q0.x, q0.y);                          // main.cpp:523-524
+                const f2 m = mk2(q0.z, q0.w) * v.x + mk2(q1.x, q1.y) * v.y;  // inv_cov * v: (a vx + b vy, b vx + d vy)
+                const f2 vm = v * m;
+                bool nonzero;
+                const float G = gauss_pow8(vm.x + vm.y, &nonzero);           // main.cpp:526-527
+                const unsigned long long on = act & __ballot(nonzero);
+                const float alpha = __builtin_amdgcn_inverse_ballot_w64(on) ? G * q2.y : 0.0f;
+                crg += (T * mk2(q1.z, q1.w)) * alpha;                        // main.cpp:529-530: (T*c)*alpha
+                cb += T * q2.x * alpha;                                      // main.cpp:531
+                T *= (1.0f - alpha);                                         // main.cpp:533
+                alive_mask &= __ballot(!(T < kMinThroughput));               // main.cpp:520, for the next splat
+                if (COUNT) n_act += (act >> lane) & 1ull;
             }
         }
-        if (!__syncthreads_or(alive ? 1 : 0)) break;
+        if (!__syncthreads_or(alive_mask != 0ull ? 1 : 0)) break;
     }
     if (inside) store_pixel<HALF>(image0, (size_t)y * g.W + x, make_float4(crg.x, crg.y, cb, 1.0f)); // .w reset, main.cpp:543-546
     if (COUNT) {
@@ -394,7 +397,6 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     __shared__ float4 s_q2[B]; // col_b, opacity, (sx^2-sy^2)/(sx^2 sy^2), sin*cos
     __shared__ float4 s_e0[B]; // cc, ss, 2sc, -2sc
     __shared__ float4 s_e1[B]; // ss, cc, 1/sx^3, 1/sy^3
-    __shared__ float s_e2[B];  // cc - ss
     __shared__ unsigned long long s_mask[4 * B]; // [wave][entry]
     __shared__ uint32_t s_idx[2][B];
     // per-wave partial gradients of the batch: written once per (wave, entry) by lane 63 with plain stores,
@@ -438,7 +440,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
 
     f2 crg = mk2(0.0f, 0.0f);                        // image1 = (0,0,0,1), main.cpp:549
     float cb = 0.0f, T = 1.0f;
-    bool alive = inside;
+    unsigned long long alive_mask = __ballot(inside); // wave-uniform, scalar registers (see the forward kernel)
     unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0;
 
     const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
@@ -462,13 +464,11 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                 s_q2[se] = make_float4(q1.w, q2.x, (sx2 - sy2) / (sx2 * sy * sy), sinT * cosT);
                 s_e0[se] = make_float4(cc, ss, sc2, -sc2);
                 s_e1[se] = make_float4(ss, cc, 1.0f / (sx2 * sx), 1.0f / (sy2 * sy));
-                s_e2[se] = cc - ss;
                 s_idx[par][se] = idx;
             }
         }
         __syncthreads();
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
-        unsigned long long alive_mask = __ballot(alive);
         unsigned long long touched = 0ull;
         if (alive_mask != 0ull || COUNT) {
             const unsigned long long my_mask = (lane < cnt) ? s_mask[w * B + lane] : 0ull;
@@ -478,17 +478,17 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                 cand &= cand - 1ull;
                 const unsigned long long wm = readlane_u64(my_mask, e);
                 if (COUNT) n_vis += (wm >> lane) & 1ull;
-                if ((wm & alive_mask) == 0ull) continue;
+                const unsigned long long act_mask = wm & alive_mask;
+                if (act_mask == 0ull) continue;
                 touched |= 1ull << e;
                 if (COUNT) n_exec += (lane == 0);
                 // Lanes this splat does not visit (main.cpp:595-598) or whose pixel is already below the throughput
                 // cut-off (main.cpp:604) run the same instructions with alpha forced to 0: then c += T*c*0 and
                 // T *= 1 are exact no-ops and every gradient term below is a multiple of alpha, i.e. exactly 0 --
                 // no divergent region, no zero-initialisation of the nine partials.
-                const bool act = __builtin_amdgcn_inverse_ballot_w64(wm) && alive;
                 if (COUNT) {
-                    n_act += act ? 1 : 0;
-                    const int na = __popcll(__ballot(act));
+                    n_act += (act_mask >> lane) & 1ull;
+                    const int na = __popcll(act_mask);
                     if (lane == 0) atomicAdd(&counters->bwd_lane_hist[na], 1ull);
                 }
                 float g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op = 0.f;
@@ -499,8 +499,11 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                     const f2 v = pxy - mk2(q0.x, q0.y);                              // main.cpp:607-608
                     const f2 m = mk2(q0.z, q0.w) * v.x + mk2(q1.x, q1.y) * v.y;      // inv_cov * v
                     const f2 vm = v * m;
-                    const float G = gauss_from_d2(vm.x + vm.y);                      // main.cpp:609-610
-                    const float alpha = act ? G * q2.y : 0.0f;                       // main.cpp:611
+                    bool nonzero;
+                    const float G = gauss_pow8(vm.x + vm.y, &nonzero);               // main.cpp:609-610
+                    // one scalar mask selects alpha (and dOpacity): visited, alive, and G not cut to 0
+                    const bool on = __builtin_amdgcn_inverse_ballot_w64(act_mask & __ballot(nonzero));
+                    const float alpha = on ? G * q2.y : 0.0f;                        // main.cpp:611
                     const f2 Trg = T * mk2(q1.z, q1.w);
                     const float Tb = T * q2.x;
                     crg += Trg * alpha;                                              // main.cpp:623-625
@@ -536,21 +539,20 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                     const f2 g_s = (ga * mk2(e1.z, e1.w)) * dots;                    // main.cpp:657-662, :677-678
                     g_sx = g_s.x;
                     g_sy = g_s.y;
-                    g_rot = (ga * q2.z) * (s_e2[e] * v.x * v.y - q2.w * (vv.x - vyy)); // main.cpp:680-685
-                    if (NEED_OP) g_op = act ? gs * G : 0.0f;                         // main.cpp:703-704
+                    g_rot = (ga * q2.z) * ((e0.x - e0.y) * v.x * v.y - q2.w * (vv.x - vyy)); // main.cpp:680-685
+                    if (NEED_OP) g_op = on ? gs * G : 0.0f;                           // main.cpp:703-704
                     T *= (1.0f - alpha);                                             // main.cpp:707
-                    alive = !(T < kMinThroughput);
+                    alive_mask &= __ballot(!(T < kMinThroughput));
                 }
                 // order of the record: pos.xy, sx, sy, rot, color.rgb, opacity (main.cpp:85-93)
                 const float tot = wave_sum8_packed<NEED_OP>(g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
                 float* part = reinterpret_cast<float*>(&s_part[w][e][0]);
                 if ((lane & 7) == 0) part[part_slot] = tot;
                 if (NEED_OP && lane == 63) part[8] = g_op;
-                alive_mask = __ballot(alive);
             }
         }
         if (lane == 0) s_touched[w] = touched;
-        const int any = __syncthreads_or(alive ? 1 : 0);
+        const int any = __syncthreads_or(alive_mask != 0ull ? 1 : 0);
         // one burst per (tile, splat): 9 consecutive floats -- float atomics into grads[idx], or (deterministic
         // mode) plain stores into this tile's own slot of the splat, summed later in a fixed order
         for (int i = tid; i < cnt * 9; i += 256) {

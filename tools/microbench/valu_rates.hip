@@ -1,107 +1,226 @@
-// valu_rates.hip -- GPU-box microbenchmark: sustained issue cost of the VALU instructions the raster kernels are
-// made of, per wave64 instruction per SIMD, at 1 and 8 resident waves per SIMD.  Build + run:
-//   hipcc -O3 --offload-arch=gfx950 tools/microbench/valu_rates.hip -o /tmp/valu_rates && /tmp/valu_rates
+// valu_rates.hip -- GPU-box microbenchmark: what one wave64 VALU instruction costs a gfx950 SIMD, for the opcodes
+// the raster kernels are made of.  For each opcode: 16 instructions per loop trip over 8 independent register chains
+// ("x8") or one dependent chain ("x1"), at 1..8 resident waves per SIMD.  Reported in cycles of the shader clock
+// measured inside the kernel (s_memtime against the 100 MHz s_memrealtime).
+//   hipcc -O3 --offload-arch=gfx950 tools/microbench/valu_rates.hip -o tools/microbench/valu_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <string>
 
-#define REP8(x) x x x x x x x x
-#define BODY(name, asmtext)                                                                         \
-    __global__ void name(float* out, int iters)                                                     \
-    {                                                                                               \
+#define ALL8(OP) OP(0) OP(1) OP(2) OP(3) OP(4) OP(5) OP(6) OP(7)
+#define X8(OP) ALL8(OP) ALL8(OP)
+#define X1(OP) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0) OP(0)
+
+#define KERNEL(name, asmtext)                                                                                        \
+    __global__ void name(float* out, unsigned long long* clk, int iters)                                             \
+    {                                                                                                                \
         float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
-        float b0 = 1.0001f, b1 = 0.9999f;                                                           \
-        for (int i = 0; i < iters; i++) {                                                           \
-            asm volatile(asmtext : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1)); \
-        }                                                                                           \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;         \
+        float b0 = 1.0001f, b1 = 0.9999f;                                                                            \
+        const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();                             \
+        for (int i = 0; i < iters; i++) {                                                                            \
+            asm volatile(asmtext                                                                                     \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)            \
+                         : "v"(b0), "v"(b1)                                                                          \
+                         : "vcc", "scc", "s20", "s21", "s22", "s23", "s24", "s25");                                         \
+        }                                                                                                            \
+        const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();                             \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                          \
     }
 
-// 16 instructions per asm block, 8 independent chains (dependent distance 8)
-BODY(k_mul, REP8("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %9\n") )
-BODY(k_mul8, "v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %9\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %9\n v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %9\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %9\n"
-             "v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %9\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %9\n v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %9\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %9\n")
-BODY(k_fma8, "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %9, %8\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %9, %8\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %9, %8\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %9, %8\n"
-             "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %9, %8\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %9, %8\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %9, %8\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %9, %8\n")
-BODY(k_dpp8, "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-             "v_add_f32_dpp %4, %4, %4 row_half_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_half_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %6, %6, %6 row_mirror row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_mirror row_mask:0xf bank_mask:0xf\n"
-             "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-             "v_add_f32_dpp %4, %4, %4 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_add_f32_dpp %5, %5, %5 row_bcast:15 row_mask:0xa bank_mask:0xf\n v_add_f32_dpp %6, %6, %6 row_bcast:31 row_mask:0xc bank_mask:0xf\n v_add_f32_dpp %7, %7, %7 row_bcast:31 row_mask:0xc bank_mask:0xf\n")
-BODY(k_swap8, "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3\n v_permlane16_swap_b32 %4, %6\n v_permlane16_swap_b32 %5, %7\n"
-              "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3\n v_permlane16_swap_b32 %4, %6\n v_permlane16_swap_b32 %5, %7\n")
-BODY(k_rcp8, "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n"
-             "v_rcp_f32 %0, %0\n v_rcp_f32 %1, %1\n v_rcp_f32 %2, %2\n v_rcp_f32 %3, %3\n v_rcp_f32 %4, %4\n v_rcp_f32 %5, %5\n v_rcp_f32 %6, %6\n v_rcp_f32 %7, %7\n")
-BODY(k_cnd8, "v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %9, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %9, vcc\n v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %9, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %9, vcc\n"
-             "v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %9, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %9, vcc\n v_cmp_lt_f32 vcc, %4, %8\n v_cndmask_b32 %5, %5, %9, vcc\n v_cmp_lt_f32 vcc, %6, %8\n v_cndmask_b32 %7, %7, %9, vcc\n")
+#define OP_MUL(n) "v_mul_f32 %" #n ", %" #n ", %8\n"
+#define OP_ADD(n) "v_add_f32 %" #n ", %" #n ", %8\n"
+#define OP_FMA(n) "v_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define OP_MOV(n) "v_mov_b32 %" #n ", %8\n"
+#define OP_ADDU(n) "v_add_u32 %" #n ", %" #n ", %8\n"
+#define OP_AND(n) "v_and_b32 %" #n ", %" #n ", %8\n"
+#define OP_LSHL_ADD(n) "v_lshl_add_u32 %" #n ", %" #n ", 1, %8\n"
+#define OP_MAX(n) "v_max_f32 %" #n ", %" #n ", %8\n"
+#define OP_RCP(n) "v_rcp_f32 %" #n ", %" #n "\n"
+#define OP_EXP(n) "v_exp_f32 %" #n ", %" #n "\n"
+#define OP_SQRT(n) "v_sqrt_f32 %" #n ", %" #n "\n"
+#define OP_CVT(n) "v_cvt_i32_f32 %" #n ", %" #n "\n"
+#define OP_DPP_QUAD(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define OP_DPP_ROWSHR(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " row_shr:4 row_mask:0xf bank_mask:0xf\n"
+#define OP_DPP_MIRROR(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " row_half_mirror row_mask:0xf bank_mask:0xf\n"
+#define OP_DPP_BCAST(n) "v_add_f32_dpp %" #n ", %" #n ", %" #n " row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+#define OP_MOV_DPP(n) "v_mov_b32_dpp %" #n ", %" #n " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+#define OP_CMP_VCC(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n"
+#define OP_CMP_SGPR(n) "v_cmp_lt_f32 s[20:21], %" #n ", %8\n"
+#define OP_CND_VCC(n) "v_cndmask_b32 %" #n ", %" #n ", %8, vcc\n"
+#define OP_CND_SGPR(n) "v_cndmask_b32 %" #n ", %" #n ", %8, s[22:23]\n"
+#define OP_READLANE(n) "v_readlane_b32 s24, %" #n ", 3\n"
+#define OP_READFIRST(n) "v_readfirstlane_b32 s24, %" #n "\n"
+#define OP_MUL_SGPR(n) "v_mul_f32 %" #n ", s25, %" #n "\n"
+#define OP_MUL_LIT(n) "v_mul_f32 %" #n ", 0x3f800347, %" #n "\n"
+#define OP_MAD64(n) "v_mad_u64_u32 v[40:41], s[20:21], %" #n ", %8, v[40:41]\n"
+#define OP_MUL_THEN_S(n) "v_mul_f32 %" #n ", %" #n ", %8\n s_and_b32 s24, s24, s25\n"
+#define OP_MUL_THEN_NOP(n) "v_mul_f32 %" #n ", %" #n ", %8\n s_nop 0\n"
 
-// packed: 8 register pairs
-__global__ void k_pk8(float* out, int iters, int mode)
+KERNEL(k_mul_x8, X8(OP_MUL))
+KERNEL(k_mul_x1, X1(OP_MUL))
+KERNEL(k_add_x8, X8(OP_ADD))
+KERNEL(k_fma_x8, X8(OP_FMA))
+KERNEL(k_fma_x1, X1(OP_FMA))
+KERNEL(k_mov_x8, X8(OP_MOV))
+KERNEL(k_addu_x8, X8(OP_ADDU))
+KERNEL(k_and_x8, X8(OP_AND))
+KERNEL(k_lshladd_x8, X8(OP_LSHL_ADD))
+KERNEL(k_max_x8, X8(OP_MAX))
+KERNEL(k_rcp_x8, X8(OP_RCP))
+KERNEL(k_exp_x8, X8(OP_EXP))
+KERNEL(k_sqrt_x8, X8(OP_SQRT))
+KERNEL(k_cvt_x8, X8(OP_CVT))
+KERNEL(k_dppquad_x8, X8(OP_DPP_QUAD))
+KERNEL(k_dppquad_x1, X1(OP_DPP_QUAD))
+KERNEL(k_dpprowshr_x8, X8(OP_DPP_ROWSHR))
+KERNEL(k_dppmirror_x8, X8(OP_DPP_MIRROR))
+KERNEL(k_dppbcast_x8, X8(OP_DPP_BCAST))
+KERNEL(k_movdpp_x8, X8(OP_MOV_DPP))
+KERNEL(k_cmpvcc_x8, X8(OP_CMP_VCC))
+KERNEL(k_cmpsgpr_x8, X8(OP_CMP_SGPR))
+KERNEL(k_cndvcc_x8, X8(OP_CND_VCC))
+KERNEL(k_cndsgpr_x8, X8(OP_CND_SGPR))
+KERNEL(k_readlane_x8, X8(OP_READLANE))
+KERNEL(k_readfirst_x8, X8(OP_READFIRST))
+KERNEL(k_mulsgpr_x8, X8(OP_MUL_SGPR))
+KERNEL(k_mullit_x8, X8(OP_MUL_LIT))
+KERNEL(k_mul_s_x8, ALL8(OP_MUL_THEN_S))
+KERNEL(k_mul_nop_x8, ALL8(OP_MUL_THEN_NOP))
+KERNEL(k_swap32_x8, "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                    "v_permlane32_swap_b32 %0, %2\n v_permlane32_swap_b32 %1, %3\n v_permlane32_swap_b32 %4, %6\n v_permlane32_swap_b32 %5, %7\n"
+                    "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
+                    "v_permlane32_swap_b32 %0, %2\n v_permlane32_swap_b32 %1, %3\n v_permlane32_swap_b32 %4, %6\n v_permlane32_swap_b32 %5, %7\n")
+KERNEL(k_swap16_x8, "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+                    "v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3\n v_permlane16_swap_b32 %4, %6\n v_permlane16_swap_b32 %5, %7\n"
+                    "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
+                    "v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3\n v_permlane16_swap_b32 %4, %6\n v_permlane16_swap_b32 %5, %7\n")
+
+// packed fp32: 8 independent register pairs
+typedef float pk2 __attribute__((ext_vector_type(2)));
+#define PK_MUL(n) "v_pk_mul_f32 %" #n ", %" #n ", %8\n"
+#define PK_ADD(n) "v_pk_add_f32 %" #n ", %" #n ", %8\n"
+#define PK_FMA(n) "v_pk_fma_f32 %" #n ", %" #n ", %8, %9\n"
+#define PK_MOV(n) "v_pk_mov_b32 %" #n ", %8, %9\n"
+#define KERNEL_PK(name, asmtext)                                                                                     \
+    __global__ void name(float* out, unsigned long long* clk, int iters)                                             \
+    {                                                                                                                \
+        pk2 a0 = {(float)threadIdx.x, 1.f}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f; \
+        pk2 b0 = {1.0001f, 0.9999f}, b1 = {0.9999f, 1.0001f};                                                        \
+        const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();                             \
+        for (int i = 0; i < iters; i++) {                                                                            \
+            asm volatile(asmtext                                                                                     \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)            \
+                         : "v"(b0), "v"(b1));                                                                        \
+        }                                                                                                            \
+        const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();                             \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }                             \
+        pk2 s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                                              \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;                                                      \
+    }
+KERNEL_PK(k_pkmul_x8, X8(PK_MUL))
+KERNEL_PK(k_pkadd_x8, X8(PK_ADD))
+KERNEL_PK(k_pkfma_x8, X8(PK_FMA))
+KERNEL_PK(k_pkmov_x8, X8(PK_MOV))
+
+// LDS: ds_read_b128 of a wave-uniform address (the raster kernels' per-entry record reads) and ds_bpermute
+__global__ void k_lds(float* out, unsigned long long* clk, int iters, int mode)
 {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 a0 = {(float)threadIdx.x, 1.f}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
-    f2 b0 = {1.0001f, 0.9999f}, b1 = {0.9999f, 1.0001f};
+    __shared__ float4 s[1024];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) s[i] = make_float4(i, 1, 2, 3);
+    __syncthreads();
+    float acc = 0;
+    int idx = threadIdx.x >> 6;
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     for (int i = 0; i < iters; i++) {
-        if (mode == 0)
-            asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %9\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %9\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %9\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %9\n"
-                         "v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %9\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %9\n v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %9\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %9\n"
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1));
-        else if (mode == 1)
-            asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %9\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %9\n v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %9\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %9\n"
-                         "v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %9\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %9\n v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %9\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %9\n"
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1));
-        else
-            asm volatile("v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %9, %8\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %9, %8\n v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %9, %8\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %9, %8\n"
-                         "v_pk_fma_f32 %0, %0, %8, %9\n v_pk_fma_f32 %1, %1, %9, %8\n v_pk_fma_f32 %2, %2, %8, %9\n v_pk_fma_f32 %3, %3, %9, %8\n v_pk_fma_f32 %4, %4, %8, %9\n v_pk_fma_f32 %5, %5, %9, %8\n v_pk_fma_f32 %6, %6, %8, %9\n v_pk_fma_f32 %7, %7, %9, %8\n"
-                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b0), "v"(b1));
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            float4 v;
+            if (mode == 0) v = s[(idx + k * 5) & 1023];                    // uniform address: broadcast read
+            else v = s[(threadIdx.x + k * 64 + idx) & 1023];               // per-lane 16-byte reads
+            acc += v.x + v.w;
+            idx = (idx + (int)v.y) & 1023;
+        }
     }
-    f2 s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
-    out[blockIdx.x * blockDim.x + threadIdx.x] = s.x + s.y;
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
 }
 
-template <typename F>
-static double time_ms(F launch)
-{
-    hipEvent_t a, b;
-    hipEventCreate(&a); hipEventCreate(&b);
-    launch();
-    hipDeviceSynchronize();
-    hipEventRecord(a);
-    launch();
-    hipEventRecord(b);
-    hipEventSynchronize(b);
-    float ms = 0;
-    hipEventElapsedTime(&ms, a, b);
-    return ms;
-}
+typedef void (*kern_t)(float*, unsigned long long*, int);
 
-int main()
+int main(int argc, char** argv)
 {
+    setvbuf(stdout, nullptr, _IONBF, 0);
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int cus = p.multiProcessorCount;
-    const double ghz = p.clockRate / 1e6;
-    printf("%s: %d CUs, %.2f GHz nominal\n", p.gcnArchName, cus, ghz);
+    printf("%s: %d CUs, %.2f GHz nominal\n", p.gcnArchName, cus, p.clockRate / 1e6);
     float* out;
-    hipMalloc(&out, sizeof(float) * 256 * cus * 8 * 4);
+    unsigned long long* clk;
+    hipMalloc(&out, sizeof(float) * 256 * cus * 8);
+    hipMalloc(&clk, 16);
     const int iters = 20000;
-    for (int wps = 1; wps <= 8; wps *= 2) { // waves per SIMD
-        const int blocks = cus * wps; // 256 threads = 4 waves = one per SIMD
-        auto report = [&](const char* name, double ms, int flops_per_lane_instr) {
-            const double insts = (double)iters * 16;            // per wave
-            const double cyc = ms * 1e-3 * ghz * 1e9;           // nominal cycles
-            printf("  %-22s waves/SIMD %d: %.2f cycles per wave-instruction per SIMD (%.2f per wave), %6.1f Tlane-op/s\n", name, wps,
-                   cyc / (insts * wps), cyc / insts, insts * wps * 4 * cus * 64.0 * flops_per_lane_instr / (ms * 1e-3) / 1e12);
-        };
-        report("v_mul_f32", time_ms([&] { hipLaunchKernelGGL(k_mul8, dim3(blocks), dim3(256), 0, 0, out, iters); }), 1);
-        report("v_fma_f32", time_ms([&] { hipLaunchKernelGGL(k_fma8, dim3(blocks), dim3(256), 0, 0, out, iters); }), 1);
-        report("v_pk_mul_f32", time_ms([&] { hipLaunchKernelGGL(k_pk8, dim3(blocks), dim3(256), 0, 0, out, iters, 0); }), 2);
-        report("v_pk_add_f32", time_ms([&] { hipLaunchKernelGGL(k_pk8, dim3(blocks), dim3(256), 0, 0, out, iters, 1); }), 2);
-        report("v_pk_fma_f32", time_ms([&] { hipLaunchKernelGGL(k_pk8, dim3(blocks), dim3(256), 0, 0, out, iters, 2); }), 2);
-        report("v_add_f32_dpp", time_ms([&] { hipLaunchKernelGGL(k_dpp8, dim3(blocks), dim3(256), 0, 0, out, iters); }), 1);
-        report("v_permlane*_swap", time_ms([&] { hipLaunchKernelGGL(k_swap8, dim3(blocks), dim3(256), 0, 0, out, iters); }), 1);
-        report("v_rcp_f32", time_ms([&] { hipLaunchKernelGGL(k_rcp8, dim3(blocks), dim3(256), 0, 0, out, iters); }), 1);
-        report("v_cmp+v_cndmask", time_ms([&] { hipLaunchKernelGGL(k_cnd8, dim3(blocks), dim3(256), 0, 0, out, iters); }), 1);
+    struct K { const char* name; kern_t fn; };
+    const std::vector<K> kernels = {
+        {"v_mul_f32 x8", k_mul_x8}, {"v_mul_f32 x1 (dependent)", k_mul_x1}, {"v_add_f32 x8", k_add_x8}, {"v_fma_f32 x8", k_fma_x8},
+        {"v_fma_f32 x1 (dependent)", k_fma_x1}, {"v_mov_b32 x8", k_mov_x8}, {"v_add_u32 x8", k_addu_x8}, {"v_and_b32 x8", k_and_x8},
+        {"v_lshl_add_u32 x8", k_lshladd_x8}, {"v_max_f32 x8", k_max_x8}, {"v_mul_f32 sgpr src", k_mulsgpr_x8}, {"v_mul_f32 literal src", k_mullit_x8},
+        {"v_rcp_f32 x8", k_rcp_x8}, {"v_exp_f32 x8", k_exp_x8}, {"v_sqrt_f32 x8", k_sqrt_x8}, {"v_cvt_i32_f32 x8", k_cvt_x8},
+        {"v_add_f32_dpp quad_perm x8", k_dppquad_x8}, {"v_add_f32_dpp quad_perm x1", k_dppquad_x1}, {"v_add_f32_dpp row_shr x8", k_dpprowshr_x8},
+        {"v_add_f32_dpp row_half_mirror", k_dppmirror_x8}, {"v_add_f32_dpp row_bcast15", k_dppbcast_x8}, {"v_mov_b32_dpp quad_perm", k_movdpp_x8},
+        {"v_cmp_lt_f32 -> vcc", k_cmpvcc_x8}, {"v_cmp_lt_f32 -> sgpr pair", k_cmpsgpr_x8}, {"v_cndmask_b32 vcc", k_cndvcc_x8},
+        {"v_cndmask_b32 sgpr pair", k_cndsgpr_x8}, {"v_readlane_b32", k_readlane_x8}, {"v_readfirstlane_b32", k_readfirst_x8},
+        {"v_permlane32_swap", k_swap32_x8}, {"v_permlane16_swap", k_swap16_x8},
+        {"v_pk_mul_f32 x8", k_pkmul_x8}, {"v_pk_add_f32 x8", k_pkadd_x8}, {"v_pk_fma_f32 x8", k_pkfma_x8}, {"v_pk_mov_b32 x8", k_pkmov_x8},
+    };
+    const std::vector<K> mixed = {{"(v_mul_f32 + s_and_b32) pairs", k_mul_s_x8}, {"(v_mul_f32 + s_nop) pairs", k_mul_nop_x8}};
+    printf("left: issue interval seen by the oldest wave of a SIMD (it wins arbitration); right: what the SIMD spends per\n"
+           "wave-instruction when W waves per SIMD run the same stream (whole-kernel time)\n");
+    printf("%-32s %8s | %s\n", "opcode", "MHz", "oldest wave: cycles/instr at W=1,2,4,8  ||  SIMD cycles/instr (kernel time x clock / instrs / W) at W=1,2,4,8");
+    hipEvent_t ev0, ev1;
+    hipEventCreate(&ev0);
+    hipEventCreate(&ev1);
+    auto run = [&](const K& k, int instr_per_trip) {
+        double wave_cyc[4], simd_cyc[4], mhz = 0;
+        int wi = 0;
+        for (int wps = 1; wps <= 8; wps *= 2, wi++) {
+            const int blocks = cus * wps;
+            unsigned long long h[2] = {0, 0};
+            for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, out, clk, iters);
+            hipEventRecord(ev0);
+            hipLaunchKernelGGL(k.fn, dim3(blocks), dim3(256), 0, 0, out, clk, iters);
+            hipEventRecord(ev1);
+            hipEventSynchronize(ev1);
+            float ms = 0;
+            hipEventElapsedTime(&ms, ev0, ev1);
+            hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+            wave_cyc[wi] = (double)h[0] / ((double)iters * instr_per_trip);
+            mhz = (double)h[0] / (double)h[1] * 100.0;
+            simd_cyc[wi] = ms * 1e-3 * mhz * 1e6 / ((double)iters * instr_per_trip * wps);
+        }
+        printf("%-32s %8.0f | %6.2f %6.2f %6.2f %6.2f  || %6.2f %6.2f %6.2f %6.2f\n", k.name, mhz, wave_cyc[0], wave_cyc[1], wave_cyc[2], wave_cyc[3],
+               simd_cyc[0], simd_cyc[1], simd_cyc[2], simd_cyc[3]);
+    };
+    for (const K& k : kernels) run(k, 16);
+    for (const K& k : mixed) run(k, 8); // per v_mul (each followed by one SALU instruction)
+    for (int mode = 0; mode < 2; mode++) {
+        double wave_cyc[4], mhz = 0;
+        int wi = 0;
+        for (int wps = 1; wps <= 8; wps *= 2, wi++) {
+            unsigned long long h[2];
+            for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(k_lds, dim3(cus * wps), dim3(256), 0, 0, out, clk, iters / 8, mode);
+            hipDeviceSynchronize();
+            hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+            wave_cyc[wi] = (double)h[0] / ((double)(iters / 8) * 16);
+            mhz = (double)h[0] / (double)h[1] * 100.0;
+        }
+        printf("%-32s %8.0f | %6.1f %6.1f %6.1f %6.1f  || %6.1f %6.1f %6.1f %6.1f   (dependent ds_read_b128 + 3 VALU)\n",
+               mode == 0 ? "ds_read_b128 uniform addr chain" : "ds_read_b128 per-lane chain", mhz, wave_cyc[0], wave_cyc[1], wave_cyc[2], wave_cyc[3],
+               wave_cyc[0], wave_cyc[1] / 2, wave_cyc[2] / 4, wave_cyc[3] / 8);
     }
     hipFree(out);
+    hipFree(clk);
     return 0;
 }
