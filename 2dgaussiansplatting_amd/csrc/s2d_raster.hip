@@ -102,6 +102,9 @@ __device__ __forceinline__ void store_pixel(void* base, size_t i, float4 c)
 #ifndef S2D_PACKED_F32
 #define S2D_PACKED_F32 0
 #endif
+#ifndef S2D_LDS_REDUCE
+#define S2D_LDS_REDUCE 1 // backward: wave-wide gradient sums through an LDS transpose (1) or the swap/DPP butterfly (0)
+#endif
 #if S2D_PACKED_F32
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
@@ -347,6 +350,75 @@ __device__ __forceinline__ float wave_sum8_packed(float a0, float a1, float a2, 
     return d;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same eight wave-wide sums through LDS (default, -DS2D_LDS_REDUCE=0 selects the butterfly above).
+// On gfx950 a v_permlane*_swap occupies the SIMD for ~8.8 cycles and a DPP add for ~4.6 against 2.4 for a plain
+// v_add_f32 (tools/microbench/valu_rates.hip), so the butterfly costs ~90 SIMD cycles per (wave, entry) of a
+// VALU-bound kernel, while the LDS pipe idles.  Here every lane stores its 8 partials component-major into a
+// wave-private scratch (element n = 64*c + lane), reads back elements 8*lane .. 8*lane+7 -- eight lanes' worth of
+// component lane>>3 -- with two 16-B reads, adds them pairwise (7 plain adds) and finishes inside its 8-lane
+// group with three DPP adds: ~31 SIMD cycles.  Afterwards every lane of group g = lane >> 3 holds the total of
+// component g.  Element n lives at dword n + 4*(n >> 5): the 16-B pad per 32 elements keeps the stride-32-B
+// reads conflict-free (lanes i and i+4 of a 16-lane pass would otherwise share banks).  Same-wave LDS accesses
+// complete in issue order, so no barrier is needed -- only the compiler is told not to reorder.
+// The ninth value (opacity gradient) takes the DPP chain to lane 63, interleaved with the group sum.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kRedStride = 72;            // dwords between components: 64 + 2 pads of 4
+constexpr int kRedDwords = 8 * kRedStride; // per wave
+
+template <bool NINTH>
+__device__ __forceinline__ float wave_sum8_lds(float* sw, int lane, float a0, float a1, float a2, float a3, float a4,
+                                               float a5, float a6, float a7, float& a8)
+{
+    float* wp = sw + lane + 4 * (lane >> 5);
+    wp[0 * kRedStride] = a0;
+    wp[1 * kRedStride] = a1;
+    wp[2 * kRedStride] = a2;
+    wp[3 * kRedStride] = a3;
+    wp[4 * kRedStride] = a4;
+    wp[5 * kRedStride] = a5;
+    wp[6 * kRedStride] = a6;
+    wp[7 * kRedStride] = a7;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float4* rp = reinterpret_cast<const float4*>(sw + 8 * lane + 4 * (lane >> 2));
+    const float4 u = rp[0], v = rp[1];
+    float t = ((u.x + u.y) + (u.z + u.w)) + ((v.x + v.y) + (v.z + v.w));
+    // the reads must have returned before the next entry's stores may be issued by the compiler
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (NINTH) {
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                     "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 0\n"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                     "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 0\n"
+                     "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                     "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     : "+v"(t), "+v"(a8));
+    } else {
+        asm volatile("s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
+                     "s_nop 1\n"
+                     : "+v"(t));
+    }
+    return t;
+}
+
 // num / den, correctly rounded, from a once-refined reciprocal r ~ 1/den shared by several numerators: the
 // hardware's IEEE division sequence (v_rcp, one Newton step on the reciprocal, quotient, two residual
 // corrections with exact fma residuals) without its per-division scaling for denormal / huge operands, which
@@ -381,8 +453,13 @@ struct DetSlots {
     uint32_t now;             // iteration + 1
 };
 
+#ifdef S2D_BWD_WAVES_PER_SIMD // A/B switch: cap the register budget so that this many waves fit a SIMD
+#define S2D_BWD_OCC __attribute__((amdgpu_waves_per_eu(S2D_BWD_WAVES_PER_SIMD, S2D_BWD_WAVES_PER_SIMD)))
+#else
+#define S2D_BWD_OCC
+#endif
 template <bool COUNT, bool NEED_OP, bool HALF, bool DET>
-__global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
+__global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
                                                               const uint32_t* __restrict__ list,
                                                               const ProjRec* __restrict__ proj,
                                                               const void* __restrict__ image0,
@@ -399,11 +476,18 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     __shared__ float4 s_e1[B]; // ss, cc, 1/sx^3, 1/sy^3
     __shared__ unsigned long long s_mask[4 * B]; // [wave][entry]
     __shared__ uint32_t s_idx[2][B];
-    // per-wave partial gradients of the batch: written once per (wave, entry) by lane 63 with plain stores,
-    // summed over the 4 waves in a fixed order by the flush.  12 floats per slot keep float4 stores aligned.
-    __shared__ float4 s_part[4][B][3];
+    // Partial gradients of the batch, 9 (+3 pad) floats per entry.  Deterministic mode: one slot per wave, plain
+    // stores, summed over the 4 waves in a fixed order by the flush.  Otherwise the four waves add into ONE slot
+    // per entry with ds_add_f32 (eight lanes, eight addresses per wave and entry): the order of those four
+    // additions is as free as the order of the global atomics that follow, and 9 KB less LDS per workgroup is
+    // one to two more resident workgroups per CU.  The flush zeroes what it read.
+    constexpr int kPartWaves = DET ? 4 : 1;
+    __shared__ float4 s_part[kPartWaves][B][3];
     __shared__ unsigned long long s_touched[4]; // bit e: wave w wrote slot e in this batch
     __shared__ double s_red[4];
+#if S2D_LDS_REDUCE
+    __shared__ __attribute__((aligned(16))) float s_xpose[4][kRedDwords]; // wave-private transpose scratch
+#endif
 
     const int tile = tile_of_block(blockIdx.x, g.num_tiles);
     if (tile < 0) return;
@@ -417,7 +501,11 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     const bool inside = x < g.W && y < g.row_end;
     const f2 pxy = mk2((float)x + 0.5f, (float)y + 0.5f);
     // after wave_sum8_packed the 8-lane group (lane >> 3) holds the total of record component bitrev3(lane >> 3)
+#if S2D_LDS_REDUCE
+    const int part_slot = lane >> 3; // after wave_sum8_lds the 8-lane group holds the total of component lane >> 3
+#else
     const int part_slot = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
+#endif
 
     float4 fin = make_float4(0.f, 0.f, 0.f, 0.f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
     if (inside) {
@@ -435,6 +523,8 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         for (int d = 32; d >= 1; d >>= 1) e2 += __shfl_down(e2, d, 64);
         if (lane == 0) s_red[w] = e2;
     }
+    if (!DET)
+        for (int i = tid; i < B * 3; i += 256) s_part[0][i / 3][i % 3] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     if (tid == 0) tile_sqerr[tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
 
@@ -545,13 +635,22 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                     alive_mask &= __ballot(!(T < kMinThroughput));
                 }
                 // order of the record: pos.xy, sx, sy, rot, color.rgb, opacity (main.cpp:85-93)
+#if S2D_LDS_REDUCE
+                const float tot = wave_sum8_lds<NEED_OP>(s_xpose[w], lane, g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
+#else
                 const float tot = wave_sum8_packed<NEED_OP>(g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
-                float* part = reinterpret_cast<float*>(&s_part[w][e][0]);
-                if ((lane & 7) == 0) part[part_slot] = tot;
-                if (NEED_OP && lane == 63) part[8] = g_op;
+#endif
+                float* part = reinterpret_cast<float*>(&s_part[DET ? w : 0][e][0]);
+                if (DET) {
+                    if ((lane & 7) == 0) part[part_slot] = tot;
+                    if (NEED_OP && lane == 63) part[8] = g_op;
+                } else {
+                    if ((lane & 7) == 0) __hip_atomic_fetch_add(part + part_slot, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (NEED_OP && lane == 63) __hip_atomic_fetch_add(part + 8, g_op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
         }
-        if (lane == 0) s_touched[w] = touched;
+        if (DET && lane == 0) s_touched[w] = touched;
         const int any = __syncthreads_or(alive_mask != 0ull ? 1 : 0);
         // one burst per (tile, splat): 9 consecutive floats -- float atomics into grads[idx], or (deterministic
         // mode) plain stores into this tile's own slot of the splat, summed later in a fixed order
@@ -560,12 +659,19 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
             if (!NEED_OP && k == 8 && !DET) continue; // dSplats.opacity left at zero on request
             float v = 0.0f;
             bool any_w = false;
+            if (DET) {
 #pragma unroll
-            for (int ww = 0; ww < 4; ww++)
-                if ((s_touched[ww] >> e) & 1ull) {
-                    v += reinterpret_cast<const float*>(&s_part[ww][e][0])[k];
-                    any_w = true;
-                }
+                for (int ww = 0; ww < kPartWaves; ww++)
+                    if ((s_touched[ww] >> e) & 1ull) {
+                        v += reinterpret_cast<const float*>(&s_part[ww][e][0])[k];
+                        any_w = true;
+                    }
+            } else {
+                float* slot = reinterpret_cast<float*>(&s_part[0][e][0]) + k;
+                v = *slot;
+                *slot = 0.0f; // the next batch's waves add after the staging barrier
+                any_w = true;
+            }
             if (DET) {
                 if (any_w) {
                     const uint32_t idx = s_idx[par][e];
