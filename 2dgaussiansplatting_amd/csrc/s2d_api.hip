@@ -246,7 +246,8 @@ int queue_backward(s2d_ctx* c, bool need_opacity_grad)
                                       c->d_wave_masks, c->d_grads,
                                       c->d_tile_sqerr, c->g, need_opacity_grad, c->deterministic ? &dg : nullptr,
                                       (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
-    S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->stream));
+    S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->d_tile_sqerr + c->g.num_tiles,
+                                     c->stream));
     c->last_sqerr_slot = slot;
     c->have_backward = true;
     return S2D_OK;
@@ -347,7 +348,8 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     c->pixel_bytes = c->half_images ? 8 : sizeof(float4);
     S2D_HIP(c, hipMalloc(&c->d_image0, px * c->pixel_bytes));
     S2D_HIP(c, hipMalloc(&c->d_ref, px * c->pixel_bytes));
-    S2D_HIP(c, dev_alloc(&c->d_tile_sqerr, (size_t)g.num_tiles));
+    S2D_HIP(c, dev_alloc(&c->d_tile_sqerr, (size_t)g.num_tiles + kSqerrScratchDoubles)); // + finalize scratch
+    S2D_HIP(c, hipMemset(c->d_tile_sqerr + g.num_tiles, 0, kSqerrScratchDoubles * sizeof(double)));
     S2D_HIP(c, dev_alloc(&c->d_sqerr_trace, (size_t)c->trace_cap));
     S2D_HIP(c, dev_alloc(&c->d_status, 1));
     S2D_HIP(c, dev_alloc(&c->d_counters, 1));
@@ -622,6 +624,8 @@ int s2d_get_stats(s2d_ctx* c, s2d_stats* out)
     out->fwd_staged = pc.fwd_staged; out->bwd_staged = pc.bwd_staged;
     out->fwd_wave_execs = pc.fwd_wave_execs; out->bwd_wave_execs = pc.bwd_wave_execs;
     for (int k = 0; k < 65; k++) out->bwd_lane_hist[k] = pc.bwd_lane_hist[k];
+    out->fwd_staged_hit = pc.fwd_staged_hit;
+    out->fwd_rows_hit = pc.fwd_rows_hit;
     out->iterations = c->iterations;
     out->first_nonfinite_iteration = c->h_status->nonfinite ? c->h_status->first_nonfinite_iter : -1;
     return S2D_OK;

@@ -39,6 +39,8 @@ struct PairCounters {
     unsigned long long fwd_visited, fwd_active, bwd_visited, bwd_active, fwd_staged, bwd_staged, fwd_wave_execs,
         bwd_wave_execs;
     unsigned long long bwd_lane_hist[65]; // executed (wave, entry) pairs by number of active lanes
+    unsigned long long fwd_staged_hit;    // staged entries with at least one pixel of the tile inside their ranges
+    unsigned long long fwd_rows_hit;      // (staged entry, tile row) pairs with a non-empty column range
 };
 
 // Device-resident status word(s), written by kernels, read by the host at synchronisation points.
@@ -154,7 +156,9 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
                                   bool need_opacity_grad, const DetGather* dg, PairCounters* counters,
                                   hipStream_t stream);
 // Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
-hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, hipStream_t stream);
+// scratch: kSqerrScratchDoubles doubles, zero before the first launch
+constexpr int kSqerrScratchDoubles = 64 + 1;
+hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, double* scratch, hipStream_t stream);
 
 // optimiser / init (s2d_optim.hip)
 hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream);

@@ -146,7 +146,7 @@ __device__ __forceinline__ void pixel_of_thread(int tid, int* lx, int* ly)
 
 // Staging thread (se = entry, sub = 0..3) evaluates tile rows sub*4 .. sub*4+3 of entry se and deposits the
 // bits into the per-(wave, entry) lane masks, laid out s_mask[wave][entry] as 2 x 32-bit words each.
-__device__ __forceinline__ void stage_masks(uint32_t* s_mask32, int se, int sub, const float4& q0, const float4& q1,
+__device__ __forceinline__ int stage_masks(uint32_t* s_mask32, int se, int sub, const float4& q0, const float4& q1,
                                             int begY, int endY, int y_tile, int x_tile, int W, int row_end)
 {
     uint32_t rm[4];
@@ -171,6 +171,7 @@ __device__ __forceinline__ void stage_masks(uint32_t* s_mask32, int se, int sub,
             s_mask32[((wy * 2 + wx) * B + se) * 2 + half] = word;
         }
     }
+    return (rm[0] != 0u) + (rm[1] != 0u) + (rm[2] != 0u) + (rm[3] != 0u); // non-empty rows (diagnostic counter)
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -213,7 +214,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
     // (A per-lane bool here costs ~15 scalar instructions per blended entry to merge with exec, and the CU's
     // single scalar unit -- not the SIMDs -- then bounds the loop; measured, profiles/r01/valu_rates.txt.)
     unsigned long long alive_mask = __ballot(inside);
-    unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0;
+    unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0, n_rows_hit = 0, n_staged_hit = 0;
 
     const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
     const int se = tid >> 2, sub = tid & 3;
@@ -222,8 +223,13 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
         if (se < cnt) {
             const ProjRec* r = proj + list[base + se];
             const float4 q0 = r->q0, q1 = r->q1, q2 = r->q2;
-            stage_masks(reinterpret_cast<uint32_t*>(s_mask), se, sub, q0, q1, __float_as_int(q2.y),
-                        __float_as_int(q2.z), ty * kTile, tx * kTile, g.W, g.row_end);
+            const int rows_hit = stage_masks(reinterpret_cast<uint32_t*>(s_mask), se, sub, q0, q1, __float_as_int(q2.y),
+                                             __float_as_int(q2.z), ty * kTile, tx * kTile, g.W, g.row_end);
+            if (COUNT) {
+                n_rows_hit += rows_hit;
+                const int entry_rows = rows_hit + __shfl_xor(rows_hit, 1) + __shfl_xor(rows_hit, 2); // the entry's 4 threads
+                n_staged_hit += (sub == 0 && entry_rows > 0) ? 1 : 0;
+            }
             if (sub == 0) {
                 s_rec[se][0] = q0;
                 s_rec[se][1] = make_float4(q0.w, q1.x, q1.y, q1.z);
@@ -270,6 +276,8 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
         atomicAdd(&counters->fwd_active, n_act);
         if (tid == 0) atomicAdd(&counters->fwd_staged, n_staged);
         if (lane == 0) atomicAdd(&counters->fwd_wave_execs, n_exec);
+        atomicAdd(&counters->fwd_rows_hit, n_rows_hit);
+        atomicAdd(&counters->fwd_staged_hit, n_staged_hit);
     }
 }
 
@@ -723,26 +731,53 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(const uint32_t* __res
     for (int k = 0; k < 9; k++) gr[k] += acc[k]; // += : the buffer is zero here unless the caller accumulates slabs
 }
 
-// One block, fixed summation order (deterministic MSE trace): 1024 threads, 8 loads in flight per thread.
-__global__ __launch_bounds__(1024) void sqerr_finalize_kernel(const double* __restrict__ tile_sqerr, int num_tiles,
-                                                              double* __restrict__ out)
+// Sum of the per-tile squared errors in a fixed order (deterministic MSE trace), two stages in one launch:
+// kSqerrBlocks blocks each reduce a contiguous chunk to partial[b]; the block that finishes last (ticket counter)
+// adds the partials, again in a fixed order, and re-arms the counter.  scratch = kSqerrBlocks doubles + one
+// 64-bit counter, zero before the first launch (s2d_api.hip allocates it behind tile_sqerr).
+constexpr int kSqerrBlocks = 64;
+
+__device__ __forceinline__ double block_sum_256(double v, double* s)
 {
-    __shared__ double s[1024];
-    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int base = threadIdx.x; base < num_tiles; base += 8 * 1024) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int i = base + j * 1024;
-            if (i < num_tiles) a[j] += tile_sqerr[i];
-        }
-    }
-    s[threadIdx.x] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
     __syncthreads();
-    for (int d = 512; d >= 1; d >>= 1) {
-        if ((int)threadIdx.x < d) s[threadIdx.x] += s[threadIdx.x + d];
-        __syncthreads();
+    return ((s[0] + s[1]) + s[2]) + s[3];
+}
+
+__global__ __launch_bounds__(256) void sqerr_finalize_kernel(const double* __restrict__ tile_sqerr, int num_tiles,
+                                                             double* __restrict__ out, double* scratch)
+{
+    __shared__ double s[4];
+    __shared__ bool last;
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(scratch + kSqerrBlocks);
+    const int chunk = (num_tiles + kSqerrBlocks - 1) / kSqerrBlocks;
+    const int beg = blockIdx.x * chunk, end = min(beg + chunk, num_tiles);
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    for (int i = beg + (int)threadIdx.x; i < end; i += 1024) {
+        a0 += tile_sqerr[i];
+        if (i + 256 < end) a1 += tile_sqerr[i + 256];
+        if (i + 512 < end) a2 += tile_sqerr[i + 512];
+        if (i + 768 < end) a3 += tile_sqerr[i + 768];
     }
-    if (threadIdx.x == 0) *out = s[0];
+    const double part = block_sum_256((a0 + a1) + (a2 + a3), s);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(scratch + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();
+        last = atomicAdd(ticket, 1ull) == (unsigned long long)(kSqerrBlocks - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const double p = threadIdx.x < kSqerrBlocks
+                         ? __hip_atomic_load(scratch + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                         : 0.0;
+    const double total = block_sum_256(p, s);
+    if (threadIdx.x == 0) {
+        *out = total;
+        *ticket = 0ull;
+    }
 }
 
 static inline unsigned raster_grid(int num_tiles) { return (unsigned)(((num_tiles + 7) / 8) * 8); }
@@ -805,9 +840,9 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
     return hipGetLastError();
 }
 
-hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, hipStream_t stream)
+hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, double* scratch, hipStream_t stream)
 {
-    hipLaunchKernelGGL(sqerr_finalize_kernel, dim3(1), dim3(1024), 0, stream, tile_sqerr, num_tiles, out);
+    hipLaunchKernelGGL(sqerr_finalize_kernel, dim3(kSqerrBlocks), dim3(256), 0, stream, tile_sqerr, num_tiles, out, scratch);
     return hipGetLastError();
 }
 

@@ -120,6 +120,8 @@ typedef struct s2d_stats {
     uint64_t bwd_lane_hist[65];              /* ... of the backward pass, by number of active lanes (0..64) */
     int32_t iterations;        /* == `iterations`, main.cpp:278 */
     int32_t first_nonfinite_iteration; /* -1 if none */
+    uint64_t fwd_staged_hit;   /* S2D_CFG_COUNT_PAIRS: staged entries that cover >= 1 pixel of their tile ... */
+    uint64_t fwd_rows_hit;     /* ... and (staged entry, tile row) pairs with a non-empty column range (of 16 per entry) */
 } s2d_stats;
 
 typedef struct s2d_ctx s2d_ctx;

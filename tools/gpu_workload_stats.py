@@ -25,6 +25,8 @@ for d in ("fwd", "bwd"):
     print("%s: staged %.1f/tile (%.0f%% of list)  visited %.1f/px  active %.1f/px  wave-execs %.1f/wave  lanes/exec %.1f" % (
         d, st[d + "_staged"] / tiles, 100.0 * st[d + "_staged"] / max(st["pairs_binned"], 1), st[d + "_visited"] / px,
         st[d + "_active"] / px, st[d + "_wave_execs"] / (tiles * 4), st[d + "_active"] / max(st[d + "_wave_execs"], 1)))
+print("fwd staging: %.0f%% of staged entries cover a pixel of their tile; %.1f of 16 tile rows non-empty per staged entry (%.1f per covering entry)" % (
+    100.0 * st["fwd_staged_hit"] / max(st["fwd_staged"], 1), st["fwd_rows_hit"] / max(st["fwd_staged"], 1), st["fwd_rows_hit"] / max(st["fwd_staged_hit"], 1)))
 h = np.array(st["bwd_lane_hist"], dtype=np.float64)
 tot = h.sum()
 cum = np.cumsum(h) / tot
