@@ -189,7 +189,7 @@ def main():
         achieved = bwd_bytes / bwd_s / 1e9 if bwd_s > 0 else 0.0
         traffic = None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp):
+        if os.path.exists(tp) and world == 1 and (W, H, n) == (4096, 4096, 1000000):  # measured for this launch only
             try:
                 traffic = json.load(open(tp)).get("raster_backward_bytes_per_launch")
             except Exception:
