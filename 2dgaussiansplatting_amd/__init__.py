@@ -45,6 +45,9 @@ class _Config(C.Structure):
                 ("rebin_interval", C.c_int32), ("rebin_margin", C.c_float), ("stream", C.c_void_p)]
 
 
+ROWS_GRADS, ROWS_SPLATS, ROWS_ADAM = 0, 1, 2  # S2D_ROWS_* (row arrays of the slab-ownership calls)
+
+
 class _Stats(C.Structure):
     _fields_ = [("pairs_binned", C.c_uint64), ("pairs_capacity", C.c_uint64), ("rebins", C.c_uint64),
                 ("fwd_visited", C.c_uint64), ("fwd_active", C.c_uint64), ("bwd_visited", C.c_uint64),
@@ -62,6 +65,7 @@ ABI_SYMBOLS = [
     "s2d_bind_grads_device", "s2d_grads_device_ptr", "s2d_get_sqerr_trace", "s2d_synchronize", "s2d_get_stats",
     "s2d_last_error", "s2d_test_sincos", "s2d_test_sort_pairs", "s2d_test_exclusive_scan",
     "s2d_debug_get_tile_lists",
+    "s2d_halo_masks", "s2d_halo_commit", "s2d_rows_gather", "s2d_rows_scatter", "s2d_grads_combine",
 ]
 
 _lib = None
@@ -108,6 +112,11 @@ def load_library(path=None):
     L.s2d_test_sort_pairs.argtypes = [i32, vp, vp, i64, i32]
     L.s2d_test_exclusive_scan.argtypes = [i32, vp, i64, vp]
     L.s2d_debug_get_tile_lists.argtypes = [vp, vp, vp, vp, i64, vp, i64]
+    L.s2d_halo_masks.argtypes = [vp, i32, vp, C.c_float, vp]
+    L.s2d_halo_commit.argtypes = [vp, vp, i32]
+    L.s2d_rows_gather.argtypes = [vp, i32, vp, i32, vp]
+    L.s2d_rows_scatter.argtypes = [vp, i32, vp, i32, vp]
+    L.s2d_grads_combine.argtypes = [vp, vp, i32, vp, i32, vp]
     if path == _build.LIB_PATH:
         _lib = L
     return L
@@ -258,6 +267,25 @@ class Trainer:
 
     def grads_device_ptr(self):
         return self.L.s2d_grads_device_ptr(self._h)
+
+    # slab ownership (include/splat2d.h, "Slab ownership"): raw DEVICE pointers in, work queued on the context's
+    # stream; distributed.HipHaloOps wraps these around torch tensors
+    def halo_masks(self, row_bounds, margin_rows, masks_ptr):
+        b = (C.c_int32 * len(row_bounds))(*row_bounds)
+        self._ck(self.L.s2d_halo_masks(self._h, len(row_bounds) - 1, b, C.c_float(margin_rows), C.c_void_p(masks_ptr)))
+
+    def halo_commit(self, masks_ptr, rank):
+        self._ck(self.L.s2d_halo_commit(self._h, C.c_void_p(masks_ptr), rank))
+
+    def rows_gather(self, what, ids_ptr, count, out_ptr):
+        self._ck(self.L.s2d_rows_gather(self._h, what, C.c_void_p(ids_ptr), count, C.c_void_p(out_ptr)))
+
+    def rows_scatter(self, what, ids_ptr, count, in_ptr):
+        self._ck(self.L.s2d_rows_scatter(self._h, what, C.c_void_p(ids_ptr), count, C.c_void_p(in_ptr)))
+
+    def grads_combine(self, rows_ptr, n_rows, src_ptr, world, recv_ptr):
+        self._ck(self.L.s2d_grads_combine(self._h, C.c_void_p(rows_ptr), n_rows, C.c_void_p(src_ptr), world,
+                                          C.c_void_p(recv_ptr)))
 
     # -- diagnostics
     def stats(self):

@@ -67,6 +67,7 @@ struct s2d_ctx {
     bool half_images = false;
     size_t pixel_bytes = sizeof(float4);
     double* d_tile_sqerr = nullptr;
+    uint8_t* d_held = nullptr; // slab ownership: 1 = this rank holds (updates) the splat; nullptr = all (s2d_halo_commit)
     double* d_sqerr_trace = nullptr;
     int trace_cap = 1 << 16;
     DeviceStatus* d_status = nullptr;
@@ -208,7 +209,7 @@ int queue_forward(s2d_ctx* c)
     if (!scheduled) {
         if (!c->proj_fresh) { // parameters changed without a fused projection: project + check now
             S2D_HIP(c, hipMemsetAsync(&c->d_status->rebin_needed, 0, sizeof(int), c->stream));
-            S2D_HIP(c, launch_project(c->d_splats, c->n, c->g, 0.0f, 1, c->d_proj, c->d_rects, c->d_counts, c->d_status,
+            S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, 0.0f, 1, c->d_proj, c->d_rects, c->d_counts, c->d_status,
                                       c->stream));
             c->proj_fresh = true;
         }
@@ -220,7 +221,7 @@ int queue_forward(s2d_ctx* c)
         rebuild = c->h_status->rebin_needed != 0;
     }
     if (rebuild) {
-        S2D_HIP(c, launch_project(c->d_splats, c->n, c->g, c->margin, 0, c->d_proj, c->d_rects, c->d_counts, c->d_status,
+        S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, c->margin, 0, c->d_proj, c->d_rects, c->d_counts, c->d_status,
                                   c->stream));
         if (int rc = rebuild_lists(c)) return rc;
         c->proj_fresh = true;
@@ -261,7 +262,7 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
     // rectangles (what the next forward needs), which saves a pass over the parameters per iteration.
     const bool fuse = c->lists_valid && c->rebin_interval > 1;
     if (fuse) S2D_HIP(c, hipMemsetAsync(&c->d_status->rebin_needed, 0, sizeof(int), c->stream));
-    S2D_HIP(c, launch_adam(c->d_splats, c->d_adams, c->d_grads, c->n, c->g, c->beta1t, c->beta2t, c->lr,
+    S2D_HIP(c, launch_adam(c->d_splats, c->d_adams, c->d_grads, c->d_held, c->n, c->g, c->beta1t, c->beta2t, c->lr,
                            (flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0, c->iterations, c->d_status,
                            fuse ? c->d_proj : nullptr, c->d_rects, c->stream));
     c->proj_fresh = fuse;
@@ -381,7 +382,7 @@ void s2d_destroy(s2d_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         void* ptrs[] = {c->d_splats, c->d_adams, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
-                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_sqerr_trace,
+                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_sqerr_trace,
                         c->d_status, c->d_counters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -583,6 +584,78 @@ int s2d_bind_grads_device(s2d_ctx* c, void* grads_device)
 }
 
 void* s2d_grads_device_ptr(s2d_ctx* c) { return c ? (void*)c->d_grads : nullptr; }
+
+// ---- slab ownership (s2d_halo.hip): all pointers below are device pointers of the caller ----
+
+int s2d_halo_masks(s2d_ctx* c, int32_t world, const int32_t* row_bounds, float margin_rows, uint32_t* masks_device)
+{
+    if (!c || !row_bounds || !masks_device || world < 1 || world > 32 || !(margin_rows >= 0.0f)) return S2D_E_INVALID;
+    for (int q = 0; q < world; q++)
+        if (row_bounds[q] > row_bounds[q + 1]) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    S2D_HIP(c, launch_halo_masks(c->d_splats, c->d_held, c->n, world, row_bounds, margin_rows, masks_device, c->stream));
+    return S2D_OK;
+}
+
+int s2d_halo_commit(s2d_ctx* c, const uint32_t* masks_device, int32_t rank)
+{
+    if (!c || !masks_device || rank < 0 || rank > 31) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    if (!c->d_held) S2D_HIP(c, dev_alloc(&c->d_held, (size_t)c->n));
+    S2D_HIP(c, launch_halo_commit(masks_device, c->n, rank, c->d_held, c->stream));
+    // splats may have arrived or left: project the held ones and rebuild the tile lists before the next forward
+    c->lists_valid = false;
+    c->proj_fresh = false;
+    c->have_forward = false;
+    c->have_backward = false;
+    return S2D_OK;
+}
+
+static int rows_base(s2d_ctx* c, int32_t what, float** base, int* w)
+{
+    switch (what) {
+    case S2D_ROWS_GRADS: *base = c->d_grads; *w = 9; return S2D_OK;
+    case S2D_ROWS_SPLATS: *base = c->d_splats; *w = 9; return S2D_OK;
+    case S2D_ROWS_ADAM: *base = c->d_adams; *w = 18; return S2D_OK;
+    default: return S2D_E_INVALID;
+    }
+}
+
+int s2d_rows_gather(s2d_ctx* c, int32_t what, const int32_t* ids_device, int32_t count, float* out_device)
+{
+    if (!c || count < 0 || (count > 0 && (!ids_device || !out_device))) return S2D_E_INVALID;
+    float* base;
+    int w;
+    if (int rc = rows_base(c, what, &base, &w)) return rc;
+    if (int rc = use_device(c)) return rc;
+    S2D_HIP(c, launch_rows_gather(base, w, ids_device, count, c->n, out_device, c->stream));
+    return S2D_OK;
+}
+
+int s2d_rows_scatter(s2d_ctx* c, int32_t what, const int32_t* ids_device, int32_t count, const float* in_device)
+{
+    if (!c || count < 0 || (count > 0 && (!ids_device || !in_device))) return S2D_E_INVALID;
+    float* base;
+    int w;
+    if (int rc = rows_base(c, what, &base, &w)) return rc;
+    if (int rc = use_device(c)) return rc;
+    S2D_HIP(c, launch_rows_scatter(base, w, ids_device, count, c->n, in_device, c->stream));
+    if (what == S2D_ROWS_SPLATS) { // parameters changed behind the projection
+        c->proj_fresh = false;
+        c->have_forward = false;
+        c->have_backward = false;
+    }
+    return S2D_OK;
+}
+
+int s2d_grads_combine(s2d_ctx* c, const int32_t* rows_device, int32_t n_rows, const int32_t* src_device, int32_t world,
+                      const float* recv_device)
+{
+    if (!c || n_rows < 0 || world < 1 || world > 32 || (n_rows > 0 && (!rows_device || !src_device))) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    S2D_HIP(c, launch_grads_combine(c->d_grads, rows_device, n_rows, src_device, world, recv_device, c->n, c->stream));
+    return S2D_OK;
+}
 
 int s2d_get_sqerr_trace(s2d_ctx* c, int32_t first_iteration, int32_t count, double* out)
 {

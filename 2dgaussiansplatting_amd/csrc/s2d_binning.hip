@@ -9,13 +9,23 @@
 
 namespace s2d {
 
-__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ splats, int n, Geometry g,
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ splats,
+                                                      const uint8_t* __restrict__ held, int n, Geometry g,
                                                       float margin, int mode, ProjRec* __restrict__ proj,
                                                       TileRect* __restrict__ rects, uint32_t* __restrict__ counts,
                                                       DeviceStatus* __restrict__ status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (held && !held[i]) { // slab ownership: another rank's splat, the local copy is stale -- it has no footprint here
+        if (mode == 0) {
+            TileRect e;
+            e.tx0 = 1; e.tx1 = 0; e.ty0 = 1; e.ty1 = 0;
+            rects[i] = e;
+            counts[i] = 0u;
+        }
+        return;
+    }
     const float* sp = splats + (size_t)i * 9;
     Splat s;
     s.pos_x = sp[0]; s.pos_y = sp[1]; s.sx = sp[2]; s.sy = sp[3]; s.rot = sp[4];
@@ -71,11 +81,11 @@ __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __res
     for (int t = prev + 1; t <= cur; t++) tile_off[t] = p;
 }
 
-hipError_t launch_project(const float* splats, int n, Geometry g, float margin, int mode, ProjRec* proj,
+hipError_t launch_project(const float* splats, const uint8_t* held, int n, Geometry g, float margin, int mode, ProjRec* proj,
                           TileRect* rects, uint32_t* counts, DeviceStatus* status, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(project_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, n, g, margin, mode, proj,
+    hipLaunchKernelGGL(project_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, held, n, g, margin, mode, proj,
                        rects, counts, status);
     return hipGetLastError();
 }

@@ -125,7 +125,7 @@ hipError_t sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, 
 // binning (s2d_binning.hip)
 // Projects every splat; mode 0: also writes rects[] (inflated by `margin` pixels) and counts[];
 // mode 1: checks that the exact rectangle lies inside rects[] and raises status->rebin_needed otherwise.
-hipError_t launch_project(const float* splats, int n, Geometry g, float margin, int mode, ProjRec* proj,
+hipError_t launch_project(const float* splats, const uint8_t* held, int n, Geometry g, float margin, int mode, ProjRec* proj,
                           TileRect* rects, uint32_t* counts, DeviceStatus* status, hipStream_t stream);
 hipError_t launch_emit_pairs(const TileRect* rects, const uint32_t* offsets, int n, Geometry g,
                              uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream);
@@ -156,6 +156,14 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
                                   bool need_opacity_grad, const DetGather* dg, PairCounters* counters,
                                   hipStream_t stream);
 // Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
+// slab ownership (s2d_halo.hip): `held` == nullptr means every splat is held (single rank, or replicated state)
+hipError_t launch_halo_masks(const float* splats, const uint8_t* held, int n, int world, const int* row_bounds, float margin,
+                             uint32_t* masks, hipStream_t stream);
+hipError_t launch_halo_commit(const uint32_t* masks, int n, int rank, uint8_t* held, hipStream_t stream);
+hipError_t launch_rows_gather(const float* base, int w, const int* ids, int count, int n, float* out, hipStream_t stream);
+hipError_t launch_rows_scatter(float* base, int w, const int* ids, int count, int n, const float* in, hipStream_t stream);
+hipError_t launch_grads_combine(float* grads, const int* rows, int n_rows, const int* src, int world, const float* recv,
+                                int n, hipStream_t stream);
 // scratch: kSqerrScratchDoubles doubles, zero before the first launch
 constexpr int kSqerrScratchDoubles = 64 + 1;
 hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, double* scratch, hipStream_t stream);
@@ -164,7 +172,7 @@ hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double
 hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream);
 // proj != nullptr: also project the UPDATED splat for the next iteration and check it against rects[]
 // (what project_kernel mode 1 would do), raising status->rebin_needed.
-hipError_t launch_adam(float* splats, float* adams, float* grads, int n, Geometry g, float beta1t, float beta2t,
+hipError_t launch_adam(float* splats, float* adams, float* grads, const uint8_t* held, int n, Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
                        const TileRect* rects, hipStream_t stream);
 hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, hipStream_t stream);

@@ -1,4 +1,10 @@
-"""Row-slab data parallelism: one process per GPU, the per-splat gradients are the only exchange.
+"""Row-slab data parallelism: one process per GPU, gradient rows are the only per-iteration exchange.
+
+Two exchange schemes over the same slab partition:
+  * SlabStep  -- splats and Adam state replicated, dense all-reduce of the N x 9 gradients (36 MB at N = 10^6);
+  * HaloStep  -- slab OWNERSHIP: a rank holds, lists and updates only the splats that can reach its rows (plus a
+                 halo margin) and exchanges gradient rows only for splats held by more than one rank (DESIGN.md
+                 section 7).  bench.py uses this one for N > 1.
 
 Partition: the image is cut into `world` contiguous slabs of whole 16-pixel tile rows; splats
 and Adam state are replicated.  Per iteration every rank rasterises its slab forward and backward (partial
@@ -44,3 +50,222 @@ def reduce_sqerr(sqerr, dist=None):
     if dist is not None:
         dist.all_reduce(sqerr)
     return sqerr
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Slab ownership with a halo (include/splat2d.h "Slab ownership", csrc/s2d_halo.hip)
+#
+# Rank q HOLDS splat i while [pos.y - reach - margin, pos.y + reach + margin] meets its rows (reach = 3*max(sx,sy)+2).
+# Invariants kept by HaloStep:
+#   (1) every rank whose rows a splat touches holds it (the margin is crossed at <= ~0.2 rows per Adam step --
+#       |step| <= lr per parameter -- and hold sets are refreshed every `rehalo_interval` iterations; a splat that
+#       arrives already touching the receiver's rows raises);
+#   (2) all holders of a splat have bit-identical parameters and Adam state: they add the holders' partial
+#       gradients in ascending rank order (ops.grads_combine) and run the same Adam kernel;
+#   (3) mask[i] (bit q = rank q holds i) is identical on all holders of i, 0 elsewhere.
+# Between refreshes the exchange lists are frozen, so an ordinary iteration costs one gather kernel, one
+# all_to_all_single with fixed split sizes and one combine kernel -- no host synchronisation.
+# ---------------------------------------------------------------------------------------------------------
+
+ROWS_GRADS, ROWS_SPLATS, ROWS_ADAM = 0, 1, 2
+_ROW_WIDTH = {ROWS_GRADS: 9, ROWS_SPLATS: 9, ROWS_ADAM: 18}
+
+
+class HipHaloOps:
+    """The row operations of HaloStep on the HIP Trainer: torch tensors in, C-ABI calls with their device pointers."""
+
+    def __init__(self, trainer, n, device):
+        import torch
+        self.torch, self.t, self.n, self.device = torch, trainer, n, device
+
+    def halo_masks(self, bounds, margin):
+        m = self.torch.empty(self.n, dtype=self.torch.int32, device=self.device)
+        self.t.halo_masks(list(bounds), float(margin), m.data_ptr())
+        return m
+
+    def halo_commit(self, mask, rank):
+        assert mask.dtype == self.torch.int32 and mask.is_contiguous() and mask.numel() == self.n
+        self.t.halo_commit(mask.data_ptr(), rank)
+
+    def rows_gather(self, what, ids, out=None):
+        k = ids.numel()
+        if out is None:
+            out = self.torch.empty((k, _ROW_WIDTH[what]), dtype=self.torch.float32, device=self.device)
+        assert ids.dtype == self.torch.int32 and ids.is_contiguous() and out.is_contiguous()
+        if k:
+            self.t.rows_gather(what, ids.data_ptr(), k, out.data_ptr())
+        return out
+
+    def rows_scatter(self, what, ids, values):
+        k = ids.numel()
+        assert ids.dtype == self.torch.int32 and ids.is_contiguous() and values.is_contiguous()
+        assert values.dtype == self.torch.float32 and values.numel() == k * _ROW_WIDTH[what]
+        if k:
+            self.t.rows_scatter(what, ids.data_ptr(), k, values.data_ptr())
+
+    def grads_combine(self, rows, src, recv):
+        k = rows.numel()
+        assert rows.dtype == self.torch.int32 and src.dtype == self.torch.int32 and src.is_contiguous() and recv.is_contiguous()
+        if k:
+            self.t.grads_combine(rows.data_ptr(), k, src.data_ptr(), src.shape[1], recv.data_ptr())
+
+
+def _all_to_all_rows(dist, recv, send, recv_rows, send_rows):
+    """all_to_all_single along dim 0 with per-rank row counts.  gloo cannot move device tensors (CPU rehearsals of
+    the GPU path only): stage through host memory there."""
+    if dist.get_backend() == "gloo" and send.is_cuda:
+        r, s = recv.cpu(), send.cpu()
+        dist.all_to_all_single(r, s, recv_rows, send_rows)
+        recv.copy_(r)
+    else:
+        dist.all_to_all_single(recv, send, recv_rows, send_rows)
+
+
+class HaloStep:
+    """One training iteration of one rank under slab ownership.  `backend`: forward() / backward() / adam_step();
+    `ops`: HipHaloOps or an equivalent (tests use an oracle-backed one)."""
+
+    def __init__(self, backend, ops, dist, rank, world, height, rehalo_interval=16, margin_rows=8.0):
+        import torch
+        self.torch = torch
+        self.backend, self.ops, self.dist = backend, ops, dist
+        self.rank, self.world = rank, world
+        self.bounds = [slab_rows(height, q, world)[0] for q in range(world)] + [height]
+        self.r0, self.r1 = self.bounds[rank], self.bounds[rank + 1]
+        self.interval, self.margin = int(rehalo_interval), float(margin_rows)
+        self.it = 0
+        self.handed_over = 0  # splats whose state this rank received or sent since the start (diagnostic)
+        assert 1 <= world <= 32 and self.interval >= 1 and self.margin >= 0.0
+        # every rank starts from the same full set of splats: no hand-over needed for the first hold sets
+        m = ops.halo_masks(self.bounds, self.margin)
+        self.mask = torch.where(((m >> rank) & 1) == 1, m, torch.zeros_like(m)).contiguous()  # invariant (3)
+        ops.halo_commit(self.mask, rank)
+        self._plan()
+
+    # -- exchange lists for the frozen hold sets
+    def _plan(self):
+        t, m, r = self.torch, self.mask, self.rank
+        mine = (m >> r) & 1
+        self.peer_ids = []
+        for p in range(self.world):
+            if p == r:
+                self.peer_ids.append(m.new_empty(0))
+            else:
+                self.peer_ids.append(t.nonzero(mine & ((m >> p) & 1)).flatten().to(t.int32))
+        self.splits = [int(x.numel()) for x in self.peer_ids]
+        total = sum(self.splits)
+        self.send_ids = t.cat(self.peer_ids) if total else m.new_empty(0)
+        dev = m.device
+        self.send_buf = t.empty((total, 9), dtype=t.float32, device=dev)
+        self.recv_buf = t.empty((total, 9), dtype=t.float32, device=dev)
+        if total:
+            rows = t.unique(self.send_ids.long(), sorted=True)
+            src = t.full((rows.numel(), self.world), -1, dtype=t.int32, device=dev)
+            src[:, r] = -2
+            base = 0
+            for p, k in enumerate(self.splits):
+                if k:
+                    pos = t.searchsorted(rows, self.peer_ids[p].long())
+                    src[pos, p] = t.arange(base, base + k, dtype=t.int32, device=dev)
+                    base += k
+            self.rows, self.src = rows.to(t.int32).contiguous(), src.contiguous()
+        else:
+            self.rows, self.src = m.new_empty(0), t.empty((0, self.world), dtype=t.int32, device=dev)
+        # skip the collective only if NO rank shares anything (all ranks must agree on calling it)
+        flag = t.tensor([total], dtype=t.int64)
+        if self.dist is not None and self.world > 1:
+            f = flag if self.dist.get_backend() == "gloo" else flag.to(dev)
+            self.dist.all_reduce(f, op=self.dist.ReduceOp.MAX)
+            flag = f.cpu()
+        self.any_exchange = int(flag.item()) > 0
+
+    def _exchange_grads(self):
+        if not self.any_exchange:
+            return
+        send = self.ops.rows_gather(ROWS_GRADS, self.send_ids, out=self.send_buf)
+        _all_to_all_rows(self.dist, self.recv_buf, send, self.splits, self.splits)
+        self.ops.grads_combine(self.rows, self.src, self.recv_buf)
+
+    # -- refresh the hold sets from the current parameters; hand the state of arriving splats over
+    def _rehalo(self):
+        t, r, ops, dist = self.torch, self.rank, self.ops, self.dist
+        old = self.mask
+        new = ops.halo_masks(self.bounds, self.margin)  # 0 where this rank holds nothing
+        held = ((old >> r) & 1) == 1
+        sender = held & ((old & (-old)) == (1 << r))    # the lowest-ranked old holder hands a splat over
+        out_ids = []
+        for q in range(self.world):
+            if q == r:
+                out_ids.append(old.new_empty(0))
+            else:
+                sel = sender & (((new >> q) & 1) == 1) & (((old >> q) & 1) == 0)
+                out_ids.append(t.nonzero(sel).flatten().to(t.int32))
+        out_rows = [int(x.numel()) for x in out_ids]
+        dev = old.device
+        cnt_out = t.tensor(out_rows, dtype=t.int64)
+        cnt_in = t.empty_like(cnt_out)
+        if dist.get_backend() == "gloo":
+            dist.all_to_all_single(cnt_in, cnt_out)
+        else:
+            co, ci = cnt_out.to(dev), cnt_in.to(dev)
+            dist.all_to_all_single(ci, co)
+            cnt_in = ci.cpu()
+        in_rows = [int(v) for v in cnt_in.tolist()]
+        ids = t.cat(out_ids) if sum(out_rows) else old.new_empty(0)
+        k = ids.numel()
+        # one row per splat: id, new mask, 9 parameters, 18 Adam moments -- as raw 32-bit words
+        pay = t.empty((k, 29), dtype=t.int32, device=dev)
+        if k:
+            pay[:, 0] = ids
+            pay[:, 1] = new[ids.long()]
+            pay[:, 2:11] = ops.rows_gather(ROWS_SPLATS, ids).view(t.int32)
+            pay[:, 11:29] = ops.rows_gather(ROWS_ADAM, ids).view(t.int32)
+        got = t.empty((sum(in_rows), 29), dtype=t.int32, device=dev)
+        _all_to_all_rows(dist, got, pay, in_rows, out_rows)
+        mask = t.where(held & (((new >> r) & 1) == 1), new, t.zeros_like(new))  # 0 for splats dropped or never held
+        if got.shape[0]:
+            rid = got[:, 0].contiguous()
+            sp = got[:, 2:11].contiguous().view(t.float32)
+            ad = got[:, 11:29].contiguous().view(t.float32)
+            reach = 3.0 * t.maximum(sp[:, 2], sp[:, 3]) + 2.0
+            touching = (sp[:, 1] + reach >= float(self.r0)) & (sp[:, 1] - reach <= float(self.r1))
+            if bool(touching.any().item()):
+                raise RuntimeError("slab ownership: %d splat(s) reached the rows of rank %d before being handed over; "
+                                   "raise margin_rows or lower rehalo_interval" % (int(touching.sum().item()), r))
+            ops.rows_scatter(ROWS_SPLATS, rid, sp)
+            ops.rows_scatter(ROWS_ADAM, rid, ad)
+            mask[rid.long()] = got[:, 1]
+        self.handed_over += k + got.shape[0]
+        self.mask = mask.contiguous()
+        ops.halo_commit(self.mask, r)
+        self._plan()
+
+    def __call__(self, after_forward=None, after_backward=None):
+        self.backend.forward()
+        if after_forward is not None:
+            after_forward()
+        self.backend.backward()
+        if after_backward is not None:
+            after_backward()
+        if self.world > 1:
+            self._exchange_grads()
+        self.backend.adam_step()
+        self.it += 1
+        if self.world > 1 and self.it % self.interval == 0:
+            self._rehalo()
+
+    # -- test / checkpoint path: the full array, every row taken from its lowest-ranked holder
+    def gather_full(self, what):
+        t, r = self.torch, self.rank
+        n = self.mask.numel()
+        vals = self.ops.rows_gather(what, t.arange(n, dtype=t.int32, device=self.mask.device))
+        own = (((self.mask >> r) & 1) == 1) & ((self.mask & (-self.mask)) == (1 << r))
+        vals = t.where(own[:, None], vals, t.zeros_like(vals))
+        if self.world > 1:
+            if self.dist.get_backend() == "gloo" and vals.is_cuda:
+                v = vals.cpu()
+                self.dist.all_reduce(v)
+                vals = v.to(vals.device)
+            else:
+                self.dist.all_reduce(vals)
+        return vals

@@ -168,6 +168,30 @@ int s2d_step(s2d_ctx* ctx, int32_t iters, uint32_t flags, double* mse_out);
 /* MSE (main.cpp:796-805) of the framebuffer produced by the last s2d_forward / s2d_backward pair. */
 int s2d_get_mse(s2d_ctx* ctx, double* mse);
 
+/* ---- Slab ownership for multi-GPU runs (no counterpart in the reference, which is single-process; DESIGN.md
+ * section 7, SURVEY.md section 8e "neighbour-only exchange").  A rank HOLDS splat i while the rows
+ * [pos.y - reach - margin, pos.y + reach + margin], reach = 3*max(sx, sy) + 2 (the circle bounding the y-range of
+ * main.cpp:489-491), meet its row slab.  Only held splats are projected, listed and updated by s2d_adam_step; the
+ * host keeps the holders' copies identical by exchanging gradient rows (and, when a splat drifts into another
+ * rank's halo, its 27-float state).  All pointers are DEVICE pointers owned by the caller; work is queued on the
+ * context's stream. */
+#define S2D_ROWS_GRADS 0  /* 9 floats per row: the gradient buffer (s2d_bind_grads_device or internal) */
+#define S2D_ROWS_SPLATS 1 /* 9 floats per row: s2d_splat */
+#define S2D_ROWS_ADAM 2   /* 18 floats per row: s2d_splat_adam */
+/* masks[i] bit q = rank q holds splat i under the current parameters (row_bounds: world+1 host ints, rank q owns
+ * rows row_bounds[q] .. row_bounds[q+1]); 0 for splats this context does not hold. world <= 32. */
+int s2d_halo_masks(s2d_ctx* ctx, int32_t world, const int32_t* row_bounds, float margin_rows, uint32_t* masks_device);
+/* This context holds exactly the splats with bit `rank` set.  Invalidates the tile lists. */
+int s2d_halo_commit(s2d_ctx* ctx, const uint32_t* masks_device, int32_t rank);
+/* out[j] = row ids[j] of the chosen array / row ids[j] = in[j] (ids distinct; out-of-range ids read 0 / are skipped) */
+int s2d_rows_gather(s2d_ctx* ctx, int32_t what, const int32_t* ids_device, int32_t count, float* out_device);
+int s2d_rows_scatter(s2d_ctx* ctx, int32_t what, const int32_t* ids_device, int32_t count, const float* in_device);
+/* grads[rows[u]] = sum over ranks q = 0..world-1, in that order, of rank q's partial: src[u*world + q] = -1 (q does
+ * not hold the row), -2 (q is this rank: the partial already in the gradient buffer), or a row index into recv.
+ * The fixed order makes the sum bit-identical on every holder. */
+int s2d_grads_combine(s2d_ctx* ctx, const int32_t* rows_device, int32_t n_rows, const int32_t* src_device, int32_t world,
+                      const float* recv_device);
+
 /* ---- multi-GPU plumbing (one process per GPU; the host all-reduces between backward and Adam) ---- */
 /* Use caller-owned DEVICE memory (n_splats * 9 floats, layout s2d_splat[n]) as the gradient buffer, so the host
  * can all-reduce it in place (RCCL).  NULL -> back to the context's own buffer.  The buffer must be zero when

@@ -99,3 +99,131 @@ def test_gloo_row_slabs_match_single_process(tmp_path, world):
     np.testing.assert_allclose(splats[0], want, rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(sq / (o.H * o.W * 3), mses, rtol=1e-6)
     assert abs(sq[0] / (o.H * o.W * 3) - mses[0]) <= 1e-12 * mses[0]  # iteration 0: same framebuffer, only the row split of the double sum differs
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Slab ownership (distributed.HaloStep): same orchestration as on GPUs, row operations done by numpy on the oracle's
+# arrays.  A small margin and a refresh every iteration make splats change hands within a few steps.
+# ---------------------------------------------------------------------------------------------------------
+class OracleHaloBackend(OracleSlabBackend):
+    """OracleSlabBackend whose Adam step leaves the splats this rank does not hold untouched."""
+
+    held = None
+
+    def adam_step(self):
+        if self.held is None:
+            return super().adam_step()
+        keep = ~self.held
+        sp, ad = self.o.splats.copy(), self.o.adams.copy()
+        assert self.o.adam() == 0
+        self.o.splats[keep] = sp[keep]
+        self.o.adams[keep] = ad[keep]
+
+
+class OracleHaloOps:
+    def __init__(self, be):
+        self.be, self.n = be, be.o.n
+        self.arr = {D.ROWS_GRADS: be.o.dsplats.view(np.float32).reshape(self.n, 9),
+                    D.ROWS_SPLATS: be.o.splats.view(np.float32).reshape(self.n, 9),
+                    D.ROWS_ADAM: be.o.adams.view(np.float32).reshape(self.n, 18)}
+
+    def halo_masks(self, bounds, margin):
+        sp = self.arr[D.ROWS_SPLATS]
+        y = sp[:, 1]
+        reach = np.float32(3.0) * np.maximum(sp[:, 2], sp[:, 3]) + np.float32(2.0) + np.float32(margin)
+        m = np.zeros(self.n, dtype=np.int32)
+        for q in range(len(bounds) - 1):
+            m |= ((y + reach >= np.float32(bounds[q])) & (y - reach <= np.float32(bounds[q + 1]))).astype(np.int32) << q
+        if self.be.held is not None:
+            m[~self.be.held] = 0
+        return torch.from_numpy(m)
+
+    def halo_commit(self, mask, rank):
+        self.be.held = ((mask.numpy() >> rank) & 1).astype(bool)
+
+    def rows_gather(self, what, ids, out=None):
+        v = torch.from_numpy(self.arr[what][ids.numpy().astype(np.int64)].copy())
+        if out is not None:
+            out.copy_(v)
+            return out
+        return v
+
+    def rows_scatter(self, what, ids, values):
+        self.arr[what][ids.numpy().astype(np.int64)] = values.numpy().reshape(len(ids), -1)
+
+    def grads_combine(self, rows, src, recv):
+        g, rows, src, recv = self.arr[D.ROWS_GRADS], rows.numpy(), src.numpy(), recv.numpy()
+        for u, i in enumerate(rows):
+            acc = None
+            for q in range(src.shape[1]):
+                s = src[u, q]
+                if s == -1:
+                    continue
+                v = g[i].copy() if s == -2 else recv[s]
+                acc = v if acc is None else (acc + v).astype(np.float32)
+            g[i] = acc
+
+
+def _halo_worker(rank, world, port, steps, n, interval, margin, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        tgt = O.target_rgba32f(O.load_s2di(os.path.join(O.GOLDEN, "squirrel_cls_mini_268x213.s2di")))
+        r0, r1 = D.slab_rows(tgt.shape[0], rank, world)
+        be = OracleHaloBackend(tgt, n, r0, r1)
+        step = D.HaloStep(be, OracleHaloOps(be), dist, rank, world, tgt.shape[0], rehalo_interval=interval,
+                          margin_rows=margin)
+        held_frac = [float(be.held.mean())]
+        for _ in range(steps):
+            step()
+            held_frac.append(float(be.held.mean()))
+        sq = D.reduce_sqerr(torch.tensor(be.sqerr, dtype=torch.float64), dist)
+        full = step.gather_full(D.ROWS_SPLATS)
+        # every rank's raw copy + mask, to check that all holders agree bit for bit
+        raw = [torch.zeros(n * 9) for _ in range(world)]
+        dist.all_gather(raw, torch.from_numpy(be.o.splats.view(np.float32).reshape(-1).copy()))
+        masks = [torch.zeros(n, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(masks, step.mask)
+        moved = torch.tensor([step.handed_over], dtype=torch.int64)
+        dist.all_reduce(moved)
+        if rank == 0:
+            np.save(out + ".full.npy", full.numpy())
+            np.save(out + ".raw.npy", np.stack([g.numpy() for g in raw]))
+            np.save(out + ".masks.npy", np.stack([m.numpy() for m in masks]))
+            np.save(out + ".sq.npy", sq.numpy())
+            np.save(out + ".meta.npy", np.array([int(moved.item()), max(held_frac) < 1.0]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,interval,margin", [(2, 1, 1.0), (3, 2, 2.0), (2, 16, 8.0)])
+def test_gloo_slab_ownership_matches_single_process(tmp_path, world, interval, margin):
+    steps, n = 12, 600
+    out = str(tmp_path / "res")
+    mp.spawn(_halo_worker, args=(world, _free_port(), steps, n, interval, margin, out), nprocs=world, join=True)
+    full, raw, masks, sq = (np.load(out + s) for s in (".full.npy", ".raw.npy", ".masks.npy", ".sq.npy"))
+    moved, _ = np.load(out + ".meta.npy")
+    raw = raw.reshape(world, n, 9)
+    # invariants: every splat has a holder; all holders carry the same mask and bit-identical parameters
+    union = np.zeros(n, dtype=np.int64)
+    for q in range(world):
+        held_q = ((masks[q] >> q) & 1).astype(bool)
+        union |= np.where(held_q, 1 << q, 0)
+    assert (union != 0).all()
+    for q in range(world):
+        held_q = ((masks[q] >> q) & 1).astype(bool)
+        assert (masks[q][held_q] == union[held_q]).all()       # a holder's mask lists exactly the holders
+        assert (masks[q][~held_q] == 0).all()
+        first = np.array([int(u & -u).bit_length() - 1 for u in union])
+        ref_rows = raw[first, np.arange(n)]
+        assert raw[q][held_q].tobytes() == ref_rows[held_q].tobytes()
+    if interval <= 2:
+        assert moved > 0, "the test is meant to exercise hand-overs"
+    # agreement with the single-process reference loop up to the fp32 summation order of the gradients
+    tgt = O.target_rgba32f(O.load_s2di(os.path.join(O.GOLDEN, "squirrel_cls_mini_268x213.s2di")))
+    o = O.OracleTrainer(tgt, n)
+    mses = [o.step()[1] for _ in range(steps)]
+    want = o.splats.view(np.float32).reshape(n, 9)
+    np.testing.assert_allclose(full, want, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(sq / (o.H * o.W * 3), mses, rtol=1e-6)

@@ -755,3 +755,94 @@ def test_repeated_forward_does_not_rebuild_lists_again():
         t.forward()
         assert t.stats()["rebins"] == r1
         assert t.get_image().tobytes() == img1.tobytes()
+
+
+# ---------------------------------------------------------------------------------------------
+# slab ownership (distributed.HaloStep) through the C ABI: several slab contexts on the one GPU, the ranks as threads
+# ---------------------------------------------------------------------------------------------
+def _run_ranks(world, W, H, n, steps, make_step, tgt=None):
+    """Runs `world` slab contexts to completion; returns per-rank dicts."""
+    import torch
+    from thread_dist import ThreadDist
+    D = importlib.import_module("2dgaussiansplatting_amd.distributed")
+    res = [None] * world
+
+    def body(rank, dist):
+        r0, r1 = D.slab_rows(H, rank, world)
+        grads = torch.zeros(n * 9, dtype=torch.float32, device="cuda")
+        with S2D.Trainer(W, H, n, row_begin=r0, row_end=r1, deterministic=True) as t:
+            t.bind_grads(grads.data_ptr())
+            if tgt is None:
+                t.set_target_synthetic()
+            else:
+                t.set_target(tgt)
+            t.init()
+            step = make_step(D, t, grads, dist, rank, world, H)
+            for _ in range(steps):
+                step()
+            torch.cuda.synchronize()
+            out = {"sq": t.sqerr_trace(0, steps), "raw": t.get_splats().view(np.float32).reshape(n, 9).copy()}
+            if hasattr(step, "gather_full"):
+                out["full"] = step.gather_full(D.ROWS_SPLATS).cpu().numpy()
+                out["adam"] = step.gather_full(D.ROWS_ADAM).cpu().numpy()
+                out["mask"] = step.mask.cpu().numpy()
+                out["moved"] = step.handed_over
+            res[rank] = out
+
+    ThreadDist(world).run(body)
+    return res
+
+
+@pytest.mark.parametrize("world,interval,margin", [(2, 1, 1.0), (3, 2, 2.0)])
+def test_slab_ownership_equals_replicated_state(world, interval, margin):
+    """HaloStep (ownership + halo exchange) against SlabStep (replicated state, dense all-reduce) on the same slabs,
+    deterministic gradients: identical holders, complete cover, hand-overs happen, and the assembled parameters
+    equal the replicated run's -- bit for bit at two ranks (a + b is the only sum either scheme forms)."""
+    W, H, n, steps = 268, 213, 1500, 10
+    tgt = mini_target()
+    halo = _run_ranks(world, W, H, n, steps, lambda D, t, g, dist, r, w, hh: D.HaloStep(
+        t, D.HipHaloOps(t, n, "cuda"), dist, r, w, hh, rehalo_interval=interval, margin_rows=margin), tgt)
+    dense = _run_ranks(world, W, H, n, steps, lambda D, t, g, dist, r, w, hh: D.SlabStep(t, g, dist), tgt)
+    union = np.zeros(n, dtype=np.int64)
+    for q in range(world):
+        union |= np.where((halo[q]["mask"] >> q) & 1, 1 << q, 0)
+    assert (union != 0).all()
+    first = np.array([int(u & -u).bit_length() - 1 for u in union])
+    canon = np.stack([halo[q]["raw"] for q in range(world)])[first, np.arange(n)]
+    for q in range(world):
+        held = ((halo[q]["mask"] >> q) & 1).astype(bool)
+        assert 0 < held.sum() < n                                   # ownership really is partial
+        assert (halo[q]["mask"][held] == union[held]).all() and not halo[q]["mask"][~held].any()
+        assert halo[q]["raw"][held].tobytes() == canon[held].tobytes()
+        assert halo[q]["full"].tobytes() == canon.tobytes()         # gather_full returns the lowest holder's rows
+    assert sum(h["moved"] for h in halo) > 0
+    for q in range(1, world):
+        assert dense[q]["raw"].tobytes() == dense[0]["raw"].tobytes()
+    sq_h = sum(h["sq"] for h in halo)
+    sq_d = sum(d["sq"] for d in dense)
+    if world == 2:
+        assert canon.tobytes() == dense[0]["raw"].tobytes()
+        assert sq_h.tobytes() == sq_d.tobytes()
+    else:  # a rank that does not hold a splat contributes an exact 0 to the dense sum: still the same additions
+        assert canon.tobytes() == dense[0]["raw"].tobytes()
+        np.testing.assert_allclose(sq_h, sq_d, rtol=1e-12)
+
+
+def test_slab_ownership_default_margin_at_size():
+    """Default refresh interval and margin on a workload with thousands of boundary splats: bit-identical to the
+    replicated scheme on the same four slabs (both add the slabs' partials in rank order; a rank that does not hold
+    a splat contributes an exact 0 there), and the MSE trace of the single-context run."""
+    W, H, n, steps = 1024, 768, 60000, 36
+    halo = _run_ranks(4, W, H, n, steps, lambda D, t, g, dist, r, w, hh: D.HaloStep(
+        t, D.HipHaloOps(t, n, "cuda"), dist, r, w, hh))
+    dense = _run_ranks(4, W, H, n, steps, lambda D, t, g, dist, r, w, hh: D.SlabStep(t, g, dist))
+    with S2D.Trainer(W, H, n, deterministic=True) as s:
+        s.set_target_synthetic(); s.init()
+        ref = np.array(s.step(steps)) * (H * W * 3)
+    sq = sum(h["sq"] for h in halo)
+    np.testing.assert_allclose(sq, ref, rtol=1e-5)
+    assert sq.tobytes() == sum(d["sq"] for d in dense).tobytes()
+    assert halo[0]["full"].tobytes() == dense[0]["raw"].tobytes()
+    assert sum(h["moved"] for h in halo) > 0
+    held = [((h["mask"] >> q) & 1).astype(bool).mean() for q, h in enumerate(halo)]
+    assert max(held) < 0.45 and sum(held) < 1.6   # a quarter of the image each, plus halos
