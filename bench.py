@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--rebin-interval", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--exchange", default="halo", choices=["halo", "dense"],
+                    help="N > 1: 'halo' = slab ownership, ranks exchange gradient rows of boundary splats only "
+                         "(distributed.HaloStep); 'dense' = replicated state, all-reduce of all N x 9 gradients")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                     "to rehearse the multi-process path with several ranks sharing one GPU)")
     args = ap.parse_args()
@@ -135,7 +138,11 @@ def main():
     t.set_target_synthetic()
     t.init()
 
-    step = D.SlabStep(t, grads, dist)  # forward, backward, all-reduce(grads), Adam
+    if world > 1 and args.exchange == "halo":
+        # forward, backward, exchange of the gradient rows of splats held by more than one rank, Adam on held splats
+        step = D.HaloStep(t, D.HipHaloOps(t, n, "cuda"), dist, rank, world, H)
+    else:
+        step = D.SlabStep(t, grads, dist)  # forward, backward, all-reduce(grads), Adam
 
     def one_step(ev=None):
         if ev is None:
@@ -209,13 +216,17 @@ def main():
             "data": "synthetic target ref(x,y)=(x/W,1-x/W,y/H); splats from the reference's init() seeds",
             "config": {"workload": "%dx%d synthetic RGB, %d Gaussians, fp32%s" % (W, H, n, " (BASELINE.json configs[3])" if (W, H, n) == (4096, 4096, 1000000) else ""),
                        "width": W, "height": H, "n_splats": n,
-                       "parallelism": "rowslab%d%s" % (world, ("+%s-allreduce-grads" % ("rccl" if args.backend == "nccl" else args.backend)) if world > 1 else ""),
+                       "parallelism": "rowslab%d%s" % (world, ("+%s-%s" % ("rccl" if args.backend == "nccl" else args.backend,
+                                                                              "halo-exchange" if args.exchange == "halo" else "allreduce-grads")) if world > 1 else ""),
                        "rebin_interval": args.rebin_interval},
             "mse_last": mse_last,
             "psnr_db_last": (10.0 * float(np.log10(255.0 ** 2 / mse_last)) if mse_last > 0 else None),
             "psnr_db_at_iteration": done + extra - 1,
             "psnr_db": (10.0 * float(np.log10(255.0 ** 2 / (float(sq200[0].item()) / (H * W * 3)))) if sq200 is not None and float(sq200[0].item()) > 0 else None),
             "iterations_total": stats["iterations"],
+            "exchange_rank0": ({"scheme": "halo", "held_fraction": float(((step.mask >> rank) & 1).float().mean().item()),
+                                "rows_exchanged_per_iteration": int(sum(step.splits)), "state_handovers": int(step.handed_over)}
+                               if isinstance(step, D.HaloStep) else {"scheme": "dense" if world > 1 else "none"}),
             "pairs_binned_rank0": stats["pairs_binned"],
             "rebins_rank0": stats["rebins"],
             "roofline": {"bound": "hbm", "kernel": "raster_backward_kernel", "achieved": achieved, "peak": 8000.0,
