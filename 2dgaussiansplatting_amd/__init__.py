@@ -113,7 +113,7 @@ def load_library(path=None):
     L.s2d_test_exclusive_scan.argtypes = [i32, vp, i64, vp]
     L.s2d_debug_get_tile_lists.argtypes = [vp, vp, vp, vp, i64, vp, i64]
     L.s2d_halo_masks.argtypes = [vp, i32, vp, C.c_float, vp]
-    L.s2d_halo_commit.argtypes = [vp, vp, i32]
+    L.s2d_halo_commit.argtypes = [vp, vp, i32, i32]
     L.s2d_rows_gather.argtypes = [vp, i32, vp, i32, vp]
     L.s2d_rows_scatter.argtypes = [vp, i32, vp, i32, vp]
     L.s2d_grads_combine.argtypes = [vp, vp, i32, vp, i32, vp]
@@ -274,8 +274,8 @@ class Trainer:
         b = (C.c_int32 * len(row_bounds))(*row_bounds)
         self._ck(self.L.s2d_halo_masks(self._h, len(row_bounds) - 1, b, C.c_float(margin_rows), C.c_void_p(masks_ptr)))
 
-    def halo_commit(self, masks_ptr, rank):
-        self._ck(self.L.s2d_halo_commit(self._h, C.c_void_p(masks_ptr), rank))
+    def halo_commit(self, masks_ptr, rank, added=1):
+        self._ck(self.L.s2d_halo_commit(self._h, C.c_void_p(masks_ptr), rank, added))
 
     def rows_gather(self, what, ids_ptr, count, out_ptr):
         self._ck(self.L.s2d_rows_gather(self._h, what, C.c_void_p(ids_ptr), count, C.c_void_p(out_ptr)))

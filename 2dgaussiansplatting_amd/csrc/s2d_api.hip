@@ -597,17 +597,20 @@ int s2d_halo_masks(s2d_ctx* c, int32_t world, const int32_t* row_bounds, float m
     return S2D_OK;
 }
 
-int s2d_halo_commit(s2d_ctx* c, const uint32_t* masks_device, int32_t rank)
+int s2d_halo_commit(s2d_ctx* c, const uint32_t* masks_device, int32_t rank, int32_t added)
 {
     if (!c || !masks_device || rank < 0 || rank > 31) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
-    if (!c->d_held) S2D_HIP(c, dev_alloc(&c->d_held, (size_t)c->n));
+    const bool first = c->d_held == nullptr;
+    if (first) S2D_HIP(c, dev_alloc(&c->d_held, (size_t)c->n));
     S2D_HIP(c, launch_halo_commit(masks_device, c->n, rank, c->d_held, c->stream));
-    // splats may have arrived or left: project the held ones and rebuild the tile lists before the next forward
-    c->lists_valid = false;
-    c->proj_fresh = false;
-    c->have_forward = false;
-    c->have_backward = false;
+    if (added || first) {
+        // splats arrived: project the held ones and rebuild the tile lists before the next forward
+        c->lists_valid = false;
+        c->proj_fresh = false;
+        c->have_forward = false;
+        c->have_backward = false;
+    }
     return S2D_OK;
 }
 

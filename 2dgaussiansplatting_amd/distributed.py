@@ -58,7 +58,8 @@ def reduce_sqerr(sqerr, dist=None):
 # Rank q HOLDS splat i while [pos.y - reach - margin, pos.y + reach + margin] meets its rows (reach = 3*max(sx,sy)+2).
 # Invariants kept by HaloStep:
 #   (1) every rank whose rows a splat touches holds it (the margin is crossed at <= ~0.2 rows per Adam step --
-#       |step| <= lr per parameter -- and hold sets are refreshed every `rehalo_interval` iterations; a splat that
+#       |step| <= lr per parameter, so the 8-row margin lasts 40 steps -- and hold sets are refreshed every
+#       `rehalo_interval` = 32 iterations; a splat that
 #       arrives already touching the receiver's rows raises);
 #   (2) all holders of a splat have bit-identical parameters and Adam state: they add the holders' partial
 #       gradients in ascending rank order (ops.grads_combine) and run the same Adam kernel;
@@ -83,9 +84,9 @@ class HipHaloOps:
         self.t.halo_masks(list(bounds), float(margin), m.data_ptr())
         return m
 
-    def halo_commit(self, mask, rank):
+    def halo_commit(self, mask, rank, added=True):
         assert mask.dtype == self.torch.int32 and mask.is_contiguous() and mask.numel() == self.n
-        self.t.halo_commit(mask.data_ptr(), rank)
+        self.t.halo_commit(mask.data_ptr(), rank, 1 if added else 0)
 
     def rows_gather(self, what, ids, out=None):
         k = ids.numel()
@@ -125,14 +126,16 @@ class HaloStep:
     """One training iteration of one rank under slab ownership.  `backend`: forward() / backward() / adam_step();
     `ops`: HipHaloOps or an equivalent (tests use an oracle-backed one)."""
 
-    def __init__(self, backend, ops, dist, rank, world, height, rehalo_interval=16, margin_rows=8.0):
+    def __init__(self, backend, ops, dist, rank, world, height, rehalo_interval=32, margin_rows=None, lr=0.05):
         import torch
         self.torch = torch
         self.backend, self.ops, self.dist = backend, ops, dist
         self.rank, self.world = rank, world
         self.bounds = [slab_rows(height, q, world)[0] for q in range(world)] + [height]
         self.r0, self.r1 = self.bounds[rank], self.bounds[rank + 1]
-        self.interval, self.margin = int(rehalo_interval), float(margin_rows)
+        self.interval = int(rehalo_interval)
+        # per Adam step |d pos.y| <= lr and |d reach| <= 3*lr: the margin must outlast one refresh interval
+        self.margin = float(margin_rows) if margin_rows is not None else max(8.0, 1.25 * self.interval * 4.0 * lr)
         self.it = 0
         self.handed_over = 0  # splats whose state this rank received or sent since the start (diagnostic)
         assert 1 <= world <= 32 and self.interval >= 1 and self.margin >= 0.0
@@ -146,16 +149,25 @@ class HaloStep:
             # once (the all-pairs count exchange opens the peer-to-peer connections) outside any timed region
             self._rehalo()
 
+    def _bit_counts(self, words):
+        """Per bit q < world: how many entries of the int32 tensor have it set (one device reduction, one sync)."""
+        t = self.torch
+        if not hasattr(self, "_shifts"):
+            self._shifts = t.arange(self.world, dtype=t.int32, device=words.device)
+        return [int(v) for v in ((words[:, None] >> self._shifts[None, :]) & 1).sum(0).tolist()]
+
     # -- exchange lists for the frozen hold sets
     def _plan(self):
         t, m, r = self.torch, self.mask, self.rank
-        mine = (m >> r) & 1
+        # m is 0 outside this rank's hold set, so bit p of m counts the rows shared with rank p: one reduction and
+        # one host read for all peers, then a nonzero() only for the (usually two) peers that share anything
+        shared = self._bit_counts(m)
         self.peer_ids = []
         for p in range(self.world):
-            if p == r:
+            if p == r or shared[p] == 0:
                 self.peer_ids.append(m.new_empty(0))
             else:
-                self.peer_ids.append(t.nonzero(mine & ((m >> p) & 1)).flatten().to(t.int32))
+                self.peer_ids.append(t.nonzero((m >> p) & 1).flatten().to(t.int32))
         self.splits = [int(x.numel()) for x in self.peer_ids]
         total = sum(self.splits)
         self.send_ids = t.cat(self.peer_ids) if total else m.new_empty(0)
@@ -197,13 +209,14 @@ class HaloStep:
         new = ops.halo_masks(self.bounds, self.margin)  # 0 where this rank holds nothing
         held = ((old >> r) & 1) == 1
         sender = held & ((old & (-old)) == (1 << r))    # the lowest-ranked old holder hands a splat over
+        arriving = t.where(sender, new & ~old, t.zeros_like(new))  # bit q: this rank hands the splat to rank q
+        n_out = self._bit_counts(arriving)
         out_ids = []
         for q in range(self.world):
-            if q == r:
+            if q == r or n_out[q] == 0:
                 out_ids.append(old.new_empty(0))
             else:
-                sel = sender & (((new >> q) & 1) == 1) & (((old >> q) & 1) == 0)
-                out_ids.append(t.nonzero(sel).flatten().to(t.int32))
+                out_ids.append(t.nonzero((arriving >> q) & 1).flatten().to(t.int32))
         out_rows = [int(x.numel()) for x in out_ids]
         dev = old.device
         cnt_out = t.tensor(out_rows, dtype=t.int64)
@@ -241,7 +254,7 @@ class HaloStep:
             mask[rid.long()] = got[:, 1]
         self.handed_over += k + got.shape[0]
         self.mask = mask.contiguous()
-        ops.halo_commit(self.mask, r)
+        ops.halo_commit(self.mask, r, added=got.shape[0] > 0)  # departures alone leave the tile lists valid
         self._plan()
 
     def __call__(self, after_forward=None, after_backward=None):

@@ -181,8 +181,10 @@ int s2d_get_mse(s2d_ctx* ctx, double* mse);
 /* masks[i] bit q = rank q holds splat i under the current parameters (row_bounds: world+1 host ints, rank q owns
  * rows row_bounds[q] .. row_bounds[q+1]); 0 for splats this context does not hold. world <= 32. */
 int s2d_halo_masks(s2d_ctx* ctx, int32_t world, const int32_t* row_bounds, float margin_rows, uint32_t* masks_device);
-/* This context holds exactly the splats with bit `rank` set.  Invalidates the tile lists. */
-int s2d_halo_commit(s2d_ctx* ctx, const uint32_t* masks_device, int32_t rank);
+/* This context holds exactly the splats with bit `rank` set.  added != 0: splats this context did not hold before
+ * are among them (their rows were written with s2d_rows_scatter): the tile lists are rebuilt before the next
+ * forward.  Splats that merely left keep their (now empty) list entries until the next regular rebuild. */
+int s2d_halo_commit(s2d_ctx* ctx, const uint32_t* masks_device, int32_t rank, int32_t added);
 /* out[j] = row ids[j] of the chosen array / row ids[j] = in[j] (ids distinct; out-of-range ids read 0 / are skipped) */
 int s2d_rows_gather(s2d_ctx* ctx, int32_t what, const int32_t* ids_device, int32_t count, float* out_device);
 int s2d_rows_scatter(s2d_ctx* ctx, int32_t what, const int32_t* ids_device, int32_t count, const float* in_device);

@@ -138,7 +138,7 @@ class OracleHaloOps:
             m[~self.be.held] = 0
         return torch.from_numpy(m)
 
-    def halo_commit(self, mask, rank):
+    def halo_commit(self, mask, rank, added=True):
         self.be.held = ((mask.numpy() >> rank) & 1).astype(bool)
 
     def rows_gather(self, what, ids, out=None):
