@@ -57,9 +57,8 @@ def reduce_sqerr(sqerr, dist=None):
 #
 # Rank q HOLDS splat i while [pos.y - reach - margin, pos.y + reach + margin] meets its rows (reach = 3*max(sx,sy)+2).
 # Invariants kept by HaloStep:
-#   (1) every rank whose rows a splat touches holds it (the margin is crossed at <= ~0.2 rows per Adam step --
-#       |step| <= lr per parameter, so the 8-row margin lasts 40 steps -- and hold sets are refreshed every
-#       `rehalo_interval` = 32 iterations; a splat that
+#   (1) every rank whose rows a splat touches holds it (the margin is sized for Adam's worst-case step, see
+#       __init__, and hold sets are refreshed every `rehalo_interval` = 32 iterations; a splat that
 #       arrives already touching the receiver's rows raises);
 #   (2) all holders of a splat have bit-identical parameters and Adam state: they add the holders' partial
 #       gradients in ascending rank order (ops.grads_combine) and run the same Adam kernel;
@@ -134,8 +133,10 @@ class HaloStep:
         self.bounds = [slab_rows(height, q, world)[0] for q in range(world)] + [height]
         self.r0, self.r1 = self.bounds[rank], self.bounds[rank + 1]
         self.interval = int(rehalo_interval)
-        # per Adam step |d pos.y| <= lr and |d reach| <= 3*lr: the margin must outlast one refresh interval
-        self.margin = float(margin_rows) if margin_rows is not None else max(8.0, 1.25 * self.interval * 4.0 * lr)
+        # Adam moves a parameter by lr*|m^|/sqrt(v^) <= 2.35*lr per step for beta = (0.9, 0.99)
+        # ((1-b1)/sqrt(1-b2) / sqrt(1 - b1^2/b2)); pos.y moves by that and reach = 3*max(sx,sy)+2 by three times
+        # that: the margin must outlast one refresh interval in the worst case (16.5 rows at 32 iterations)
+        self.margin = float(margin_rows) if margin_rows is not None else max(8.0, 1.1 * 2.35 * 4.0 * lr * self.interval)
         self.it = 0
         self.handed_over = 0  # splats whose state this rank received or sent since the start (diagnostic)
         assert 1 <= world <= 32 and self.interval >= 1 and self.margin >= 0.0
