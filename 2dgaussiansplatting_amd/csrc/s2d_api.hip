@@ -57,7 +57,9 @@ struct s2d_ctx {
     uint64_t rebins = 0;
     bool lists_valid = false;
     bool proj_fresh = false; // d_proj and d_status->rebin_needed describe the CURRENT parameters
-    hipEvent_t ev_flag = nullptr;
+    hipEvent_t ev_flag = nullptr;  // recorded behind the kernel that ran the latest containment check
+    int check_seq = 1;             // its sequence number (both stamp words start at 0: nothing matches before a check): the stamp that kernel writes if a splat left its rectangle
+    int* h_rebin_stamp = nullptr;  // host-mapped copy of that stamp (written by the kernel, read after ev_flag)
     int rebin_interval = 1;
     int since_rebin = 0;
     float margin = 0.0f;
@@ -188,19 +190,22 @@ int rebuild_lists(s2d_ctx* c)
 // Forward pass on lists that are known to cover the current parameters.
 int launch_forward(s2d_ctx* c, const int* abort_flag)
 {
+    const int abort_stamp = c->check_seq;
     S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->half_images, c->d_wave_masks,
-                                     c->g, abort_flag, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr,
+                                     c->g, abort_flag, abort_stamp, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr,
                                      c->stream));
     return S2D_OK;
 }
 
 // Project the splats, make sure the tile lists cover them, run the forward raster.
 //
-// Steady state (lists re-used): the projection of the current parameters and the containment flag were produced by
-// the Adam kernel of the previous iteration.  The forward kernel is launched OPTIMISTICALLY, right behind an
-// asynchronous copy of that flag: the kernel reads the flag on the device and does nothing if it is set, and the
-// host looks at its copy only after the launch, so the GPU never waits for the host.  If the flag was set the
-// lists are rebuilt and the forward kernel is launched again.
+// Steady state (lists re-used): the projection of the current parameters and the containment check were produced by
+// the Adam kernel of the previous iteration, which stamps a device word and a host-mapped word with the check's
+// sequence number if some splat left its binned rectangle.  The forward kernel is launched OPTIMISTICALLY: it
+// compares the device word with that sequence number and does nothing on a match, and the host reads its word only
+// after the launch (waiting for the CHECKING kernel, not the forward kernel), so the GPU never waits for the host and
+// no flag has to be copied or cleared.  If the check failed the lists are rebuilt and the forward kernel is
+// launched again.
 int queue_forward(s2d_ctx* c)
 {
     if (!c->have_target) return fail(c, S2D_E_STATE, "no target image set (s2d_set_target)");
@@ -208,25 +213,22 @@ int queue_forward(s2d_ctx* c)
     bool rebuild = scheduled;
     if (!scheduled) {
         if (!c->proj_fresh) { // parameters changed without a fused projection: project + check now
-            S2D_HIP(c, hipMemsetAsync(&c->d_status->rebin_needed, 0, sizeof(int), c->stream));
+            c->check_seq++;
             S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, 0.0f, 1, c->d_proj, c->d_rects, c->d_counts, c->d_status,
-                                      c->stream));
+                                      c->check_seq, c->h_rebin_stamp, c->stream));
+            S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
             c->proj_fresh = true;
         }
-        S2D_HIP(c, hipMemcpyAsync(&c->h_status->rebin_needed, &c->d_status->rebin_needed, sizeof(int),
-                                  hipMemcpyDeviceToHost, c->stream));
-        S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
         if (int rc = launch_forward(c, &c->d_status->rebin_needed)) return rc;
-        S2D_HIP(c, hipEventSynchronize(c->ev_flag)); // the copy, not the kernel
-        rebuild = c->h_status->rebin_needed != 0;
+        S2D_HIP(c, hipEventSynchronize(c->ev_flag)); // the checking kernel, not the forward kernel
+        rebuild = *(volatile int*)c->h_rebin_stamp == c->check_seq;
     }
     if (rebuild) {
         S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, c->margin, 0, c->d_proj, c->d_rects, c->d_counts, c->d_status,
-                                  c->stream));
+                                  0, nullptr, c->stream));
         if (int rc = rebuild_lists(c)) return rc;
         c->proj_fresh = true;
-        // the new lists cover the current parameters: the flag that asked for them is spent
-        S2D_HIP(c, hipMemsetAsync(&c->d_status->rebin_needed, 0, sizeof(int), c->stream));
+        c->check_seq++; // the new lists cover the current parameters: a stamp that asked for them matches nothing now
         if (int rc = launch_forward(c, nullptr)) return rc;
     }
     c->have_forward = true;
@@ -261,10 +263,11 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
     // With re-usable lists the Adam kernel also projects the updated splats and checks them against their binned
     // rectangles (what the next forward needs), which saves a pass over the parameters per iteration.
     const bool fuse = c->lists_valid && c->rebin_interval > 1;
-    if (fuse) S2D_HIP(c, hipMemsetAsync(&c->d_status->rebin_needed, 0, sizeof(int), c->stream));
+    if (fuse) c->check_seq++;
     S2D_HIP(c, launch_adam(c->d_splats, c->d_adams, c->d_grads, c->d_held, c->n, c->g, c->beta1t, c->beta2t, c->lr,
                            (flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0, c->iterations, c->d_status,
-                           fuse ? c->d_proj : nullptr, c->d_rects, c->stream));
+                           fuse ? c->d_proj : nullptr, c->d_rects, c->check_seq, c->h_rebin_stamp, c->stream));
+    if (fuse) S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
     c->proj_fresh = fuse;
     c->iterations++; // main.cpp:809
     c->since_rebin++;
@@ -357,6 +360,8 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, hipEventCreateWithFlags(&c->ev_flag, hipEventDisableTiming));
     S2D_HIP(c, hipHostMalloc((void**)&c->h_total, 64, hipHostMallocDefault));
     S2D_HIP(c, hipHostMalloc((void**)&c->h_status, sizeof(DeviceStatus), hipHostMallocDefault));
+    S2D_HIP(c, hipHostMalloc((void**)&c->h_rebin_stamp, 64, hipHostMallocMapped));
+    *c->h_rebin_stamp = 0;
 
     S2D_HIP(c, hipMemsetAsync(c->d_splats, 0, n * 9 * sizeof(float), c->stream));
     S2D_HIP(c, hipMemsetAsync(c->d_adams, 0, n * 18 * sizeof(float), c->stream));
@@ -389,6 +394,7 @@ void s2d_destroy(s2d_ctx* c)
         if (c->ev_flag) (void)hipEventDestroy(c->ev_flag);
         if (c->h_total) (void)hipHostFree(c->h_total);
         if (c->h_status) (void)hipHostFree(c->h_status);
+        if (c->h_rebin_stamp) (void)hipHostFree(c->h_rebin_stamp);
         if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     }
     delete c;

@@ -13,7 +13,8 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
                                                       const uint8_t* __restrict__ held, int n, Geometry g,
                                                       float margin, int mode, ProjRec* __restrict__ proj,
                                                       TileRect* __restrict__ rects, uint32_t* __restrict__ counts,
-                                                      DeviceStatus* __restrict__ status)
+                                                      DeviceStatus* __restrict__ status, int check_stamp,
+                                                      int* __restrict__ host_stamp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
         rects[i] = r;
         counts[i] = cnt;
     } else {
-        if (!rect_still_covers(p, g, rects[i])) atomicOr(&status->rebin_needed, 1);
+        if (!rect_still_covers(p, g, rects[i])) raise_rebin(status, check_stamp, host_stamp);
     }
 }
 
@@ -82,11 +83,12 @@ __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __res
 }
 
 hipError_t launch_project(const float* splats, const uint8_t* held, int n, Geometry g, float margin, int mode, ProjRec* proj,
-                          TileRect* rects, uint32_t* counts, DeviceStatus* status, hipStream_t stream)
+                          TileRect* rects, uint32_t* counts, DeviceStatus* status, int check_stamp, int* host_stamp,
+                          hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(project_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, held, n, g, margin, mode, proj,
-                       rects, counts, status);
+                       rects, counts, status, check_stamp, host_stamp);
     return hipGetLastError();
 }
 

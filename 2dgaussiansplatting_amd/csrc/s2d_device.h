@@ -47,12 +47,22 @@ struct PairCounters {
 struct DeviceStatus {
     int nonfinite;            // 1 once a checked parameter became non-finite (main.cpp:752-785)
     int first_nonfinite_iter; // iteration at which that first happened (INT_MAX if never)
-    int rebin_needed;         // a splat's exact tile rectangle left its binned rectangle
+    int rebin_needed;         // sequence number of the last containment check in which a splat's exact tile
+                              // rectangle had left its binned one (a stamp, never cleared: no memset per iteration)
     int pad;
 };
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ float as_f(int v) { return __int_as_float(v); }
+
+// A containment check found a splat outside its binned rectangle: stamp the device word the optimistically launched
+// forward kernel compares against, and the host-mapped word the host reads once the checking kernel has completed
+// (every writer stores the same value, so plain stores suffice).
+__device__ __forceinline__ void raise_rebin(DeviceStatus* status, int stamp, int* host_stamp)
+{
+    __hip_atomic_store(&status->rebin_needed, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (host_stamp) __hip_atomic_store(host_stamp, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ ProjRec pack_proj(const Projected& p)
 {
@@ -126,7 +136,8 @@ hipError_t sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, 
 // Projects every splat; mode 0: also writes rects[] (inflated by `margin` pixels) and counts[];
 // mode 1: checks that the exact rectangle lies inside rects[] and raises status->rebin_needed otherwise.
 hipError_t launch_project(const float* splats, const uint8_t* held, int n, Geometry g, float margin, int mode, ProjRec* proj,
-                          TileRect* rects, uint32_t* counts, DeviceStatus* status, hipStream_t stream);
+                          TileRect* rects, uint32_t* counts, DeviceStatus* status, int check_stamp, int* host_stamp,
+                          hipStream_t stream);
 hipError_t launch_emit_pairs(const TileRect* rects, const uint32_t* offsets, int n, Geometry g,
                              uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream);
 hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, int num_tiles,
@@ -137,7 +148,7 @@ hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, 
 // would walk are stale and the host rebuilds them and launches again.
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
                                  bool half_images, unsigned long long* wave_masks, Geometry g, const int* abort_flag,
-                                 PairCounters* counters, hipStream_t stream);
+                                 int abort_stamp, PairCounters* counters, hipStream_t stream);
 // Deterministic gradient accumulation (S2D_CFG_DETERMINISTIC): instead of float atomics every tile stores its
 // partial gradient of a splat into the slot offsets[splat] + (position of the tile in the splat's emission
 // rectangle), stamped with the iteration; a gather kernel then sums each splat's stamped slots in slot order.
@@ -174,7 +185,7 @@ hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, 
 // (what project_kernel mode 1 would do), raising status->rebin_needed.
 hipError_t launch_adam(float* splats, float* adams, float* grads, const uint8_t* held, int n, Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
-                       const TileRect* rects, hipStream_t stream);
+                       const TileRect* rects, int check_stamp, int* host_stamp, hipStream_t stream);
 hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, hipStream_t stream);
 // RGBA32F <-> 4 x fp16 (round to nearest even) for images that cross the boundary as floats
 hipError_t launch_convert_f32_to_f16(const float4* src, void* dst, size_t pixels, hipStream_t stream);

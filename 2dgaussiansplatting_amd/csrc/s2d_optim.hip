@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
                                                    Geometry g, float beta1t,
                                                    float beta2t, float lr, int optimize_opacity, int iteration,
                                                    DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
-                                                   const TileRect* __restrict__ rects)
+                                                   const TileRect* __restrict__ rects, int check_stamp,
+                                                   int* __restrict__ host_stamp)
 {
     const int W = g.W, H = g.H;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
         s.col_r = v[5]; s.col_g = v[6]; s.col_b = v[7]; s.opacity = v[8];
         const Projected p = project(s);
         proj[i] = pack_proj(p);
-        if (!rect_still_covers(p, g, rects[i])) atomicOr(&status->rebin_needed, 1);
+        if (!rect_still_covers(p, g, rects[i])) raise_rebin(status, check_stamp, host_stamp);
     }
 }
 
@@ -148,11 +149,11 @@ hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, 
 hipError_t launch_adam(float* splats, float* adams, float* grads, const uint8_t* held, int n, Geometry g, float beta1t,
                        float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
-                       const TileRect* rects, hipStream_t stream)
+                       const TileRect* rects, int check_stamp, int* host_stamp, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, held, n, g, beta1t,
-                       beta2t, lr, optimize_opacity, iteration, status, proj, rects);
+                       beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp);
     return hipGetLastError();
 }
 

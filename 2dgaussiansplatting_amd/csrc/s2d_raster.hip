@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                                                              const ProjRec* __restrict__ proj,
                                                              void* __restrict__ image0,
                                                              unsigned long long* __restrict__ wave_masks, Geometry g,
-                                                             const int* __restrict__ abort_flag,
+                                                             const int* __restrict__ abort_flag, int abort_stamp,
                                                              PairCounters* __restrict__ counters)
 {
     // per-entry record, three 16-B rows at one LDS address (one address register for the blend loop's reads):
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
     // Optimistic launch: the host queues this kernel before it has seen the containment flag the previous Adam
     // (or projection) kernel produced.  If some splat left its binned rectangle the lists are stale: do nothing;
     // the host rebuilds them and launches again.  The flag is final before this kernel starts (stream order).
-    if (abort_flag != nullptr && *abort_flag != 0) return;
+    if (abort_flag != nullptr && *abort_flag == abort_stamp) return;
     const int tile = tile_of_block(blockIdx.x, g.num_tiles);
     if (tile < 0) return;
     const int tx = tile % g.tiles_x;
@@ -784,17 +784,18 @@ static inline unsigned raster_grid(int num_tiles) { return (unsigned)(((num_tile
 
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
                                  bool half_images, unsigned long long* wave_masks, Geometry g, const int* abort_flag,
+                                 int abort_stamp,
                                  PairCounters* counters, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
 #if S2D_PPL == 2
     const dim3 grid(raster_grid(g.num_tiles)), block(kBlock2);
 #define S2D_LAUNCH_FWD(C, H) \
-    hipLaunchKernelGGL((raster_forward2_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, abort_flag, counters)
+    hipLaunchKernelGGL((raster_forward2_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, abort_flag, abort_stamp, counters)
 #else
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
 #define S2D_LAUNCH_FWD(C, H) \
-    hipLaunchKernelGGL((raster_forward_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, abort_flag, counters)
+    hipLaunchKernelGGL((raster_forward_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, abort_flag, abort_stamp, counters)
 #endif
     if (counters) {
         if (half_images) S2D_LAUNCH_FWD(true, true); else S2D_LAUNCH_FWD(true, false);

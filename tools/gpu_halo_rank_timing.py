@@ -36,9 +36,11 @@ def main():
     W = H = 4096
     n = 1000000
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 96
-    for world in (1, 2, 4, 8):
+    worlds = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2, 4, 8]
+    schemes = sys.argv[3].split(",") if len(sys.argv) > 3 else None
+    for world in worlds:
         rank = world // 2
-        for scheme in (("halo", "dense") if world > 1 else ("single",)):
+        for scheme in (schemes or (("halo", "dense") if world > 1 else ("single",))):
             stream = torch.cuda.Stream()
             torch.cuda.set_stream(stream)
             r0, r1 = D.slab_rows(H, rank, world)
