@@ -69,6 +69,10 @@ struct s2d_ctx {
     bool half_images = false;
     size_t pixel_bytes = sizeof(float4);
     double* d_tile_sqerr = nullptr;
+    uint32_t* d_order_buf = nullptr;  // 4 x num_tiles: keys/vals double buffer for the longest-first tile order
+    uint32_t* d_order_temp = nullptr;
+    bool order_tiles = false;         // S2D_TILE_ORDER=1 in the environment: dispatch tiles longest list first.
+                                      // Measured: 438 vs 444 it/s at 4096^2/1M, no change on a 1/8 slab -- off.
     uint8_t* d_held = nullptr; // slab ownership: 1 = this rank holds (updates) the splat; nullptr = all (s2d_halo_commit)
     double* d_sqerr_trace = nullptr;
     int trace_cap = 1 << 16;
@@ -181,6 +185,15 @@ int rebuild_lists(s2d_ctx* c)
     S2D_HIP(c, launch_tile_offsets(k_out, (uint32_t)total, c->g.num_tiles, c->d_tile_off, c->stream));
     c->d_list = v_out;
     c->pairs = total;
+    c->g.tile_order = nullptr;
+    if (c->order_tiles && c->g.num_tiles > 1) {
+        const size_t nt = (size_t)c->g.num_tiles;
+        uint32_t *ok = nullptr, *ov = nullptr;
+        S2D_HIP(c, launch_tile_order_keys(c->d_tile_off, c->g.num_tiles, c->d_order_buf, c->d_order_buf + nt, c->stream));
+        S2D_HIP(c, sort_pairs_u32(c->d_order_buf, c->d_order_buf + nt, c->d_order_buf + 2 * nt, c->d_order_buf + 3 * nt,
+                                  (int64_t)nt, 16, c->d_order_temp, &ok, &ov, c->stream));
+        c->g.tile_order = ov;
+    }
     c->rebins++;
     c->lists_valid = true;
     c->since_rebin = 0;
@@ -347,6 +360,9 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, dev_alloc(&c->d_scan_temp, scan_temp_words((int64_t)n)));
     S2D_HIP(c, dev_alloc(&c->d_total, 4));
     S2D_HIP(c, dev_alloc(&c->d_tile_off, (size_t)g.num_tiles + 1));
+    S2D_HIP(c, dev_alloc(&c->d_order_buf, (size_t)g.num_tiles * 4));
+    S2D_HIP(c, dev_alloc(&c->d_order_temp, sort_temp_words((int64_t)g.num_tiles)));
+    if (const char* e = getenv("S2D_TILE_ORDER")) c->order_tiles = e[0] != '0';
     c->deterministic = (cfg->flags & S2D_CFG_DETERMINISTIC) != 0;
     c->half_images = (cfg->flags & S2D_CFG_FP16_IMAGES) != 0;
     c->pixel_bytes = c->half_images ? 8 : sizeof(float4);
@@ -387,7 +403,7 @@ void s2d_destroy(s2d_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         void* ptrs[] = {c->d_splats, c->d_adams, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
-                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_sqerr_trace,
+                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_order_buf, c->d_order_temp, c->d_sqerr_trace,
                         c->d_status, c->d_counters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);

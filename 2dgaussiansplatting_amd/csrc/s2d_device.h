@@ -33,6 +33,9 @@ struct Geometry {
     int trow0;          // row_begin / 16: first global tile row of the slab
     int tiles_y;        // tile rows in the slab
     int num_tiles;      // tiles_x * tiles_y
+    // Dispatch order of the raster kernels: block b works on tile tile_order[b] (nullptr: tile b).  Rebuilt with the
+    // tile lists, longest list first, so that the last round of workgroups is made of short tiles (speed only).
+    const uint32_t* tile_order;
 };
 
 struct PairCounters {
@@ -131,6 +134,10 @@ size_t sort_temp_words(int64_t n);
 hipError_t sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int64_t n,
                           int key_bits, uint32_t* temp, uint32_t** keys_out, uint32_t** vals_out,
                           hipStream_t stream);
+
+// keys[t] = 0xFFFF - min(list length of tile t, 0xFFFF), vals[t] = t: sorting by these 16-bit keys orders the tiles
+// longest list first (s2d_binning.hip)
+hipError_t launch_tile_order_keys(const uint32_t* tile_off, int num_tiles, uint32_t* keys, uint32_t* vals, hipStream_t stream);
 
 // binning (s2d_binning.hip)
 // Projects every splat; mode 0: also writes rects[] (inflated by `margin` pixels) and counts[];

@@ -45,14 +45,15 @@ static_assert(kWaveW == 16 || kWaveW == 8, "wave block is 16x4 or 8x8");
 // neighbouring tiles, which share most of their splat records, hit the same L2: measured 1.7 % SLOWER at
 // 4096^2 / 1 M (352 vs 358 it/s) because these kernels are VALU-issue-bound, not L2-bound, and the contiguous
 // runs balance worse.  Kept as a switch for memory-bound configurations.  Speed only, never correctness.
-__device__ __forceinline__ int tile_of_block(int bid, int num_tiles)
+__device__ __forceinline__ int tile_of_block(int bid, const Geometry& g)
 {
 #ifdef S2D_XCD_REMAP
-    const int per = (num_tiles + 7) >> 3;
+    const int per = (g.num_tiles + 7) >> 3;
     const int t = (bid & 7) * per + (bid >> 3);
-    return t < num_tiles ? t : -1;
+    return t < g.num_tiles ? t : -1;
 #else
-    return bid < num_tiles ? bid : -1;
+    if (bid >= g.num_tiles) return -1;
+    return g.tile_order ? (int)g.tile_order[bid] : bid;
 #endif
 }
 
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
     // (or projection) kernel produced.  If some splat left its binned rectangle the lists are stale: do nothing;
     // the host rebuilds them and launches again.  The flag is final before this kernel starts (stream order).
     if (abort_flag != nullptr && *abort_flag == abort_stamp) return;
-    const int tile = tile_of_block(blockIdx.x, g.num_tiles);
+    const int tile = tile_of_block(blockIdx.x, g);
     if (tile < 0) return;
     const int tx = tile % g.tiles_x;
     const int ty = tile / g.tiles_x + g.trow0;
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
     __shared__ __attribute__((aligned(16))) float s_xpose[4][kRedDwords]; // wave-private transpose scratch
 #endif
 
-    const int tile = tile_of_block(blockIdx.x, g.num_tiles);
+    const int tile = tile_of_block(blockIdx.x, g);
     if (tile < 0) return;
     const int tx = tile % g.tiles_x;
     const int ty = tile / g.tiles_x + g.trow0;
