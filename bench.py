@@ -250,6 +250,9 @@ def main():
             out["compute"] = {"unit": "TFLOP/s", "achieved": flops * its / 1e12, "peak": 157.3,
                               "frac": flops * its / 1e12 / 157.3, "active_pairs_per_pass": cs["bwd_active"],
                               "lanes_per_executed_wave_entry": cs["bwd_active"] / max(cs["bwd_wave_execs"], 1),
+                              # backward kernel against the measured gfx950 instruction costs (DESIGN.md section 4,
+                              # profiles/r01/valu_rates.txt): ~290 SIMD cycles per executed (wave, entry), 1024 SIMDs
+                              "bwd_simd_busy_model": (cs["bwd_wave_execs"] * 290.0) / (1024 * 2.4e9 * bwd_s) if bwd_s > 0 else None,
                               "note": "useful fp32 VALU flops only; kernels are VALU-issue-bound (DESIGN.md section 4)"}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or host_cores()
