@@ -846,3 +846,65 @@ def test_slab_ownership_default_margin_at_size():
     assert sum(h["moved"] for h in halo) > 0
     held = [((h["mask"] >> q) & 1).astype(bool).mean() for q, h in enumerate(halo)]
     assert max(held) < 0.45 and sum(held) < 1.6   # a quarter of the image each, plus halos
+
+
+def test_row_level_abi_calls_against_numpy():
+    """s2d_rows_gather / s2d_rows_scatter / s2d_grads_combine / s2d_halo_masks / s2d_halo_commit, one by one."""
+    import torch
+    D = importlib.import_module("2dgaussiansplatting_amd.distributed")
+    W, H, n = 268, 213, 1000
+    rng = np.random.default_rng(5)
+    with S2D.Trainer(W, H, n) as t:
+        t.set_target(mini_target())
+        t.init()
+        ops = D.HipHaloOps(t, n, "cuda")
+        sp = t.get_splats().view(np.float32).reshape(n, 9)
+        ids = torch.from_numpy(rng.permutation(n)[:300].astype(np.int32)).cuda()
+        got = ops.rows_gather(D.ROWS_SPLATS, ids).cpu().numpy()
+        assert got.tobytes() == sp[ids.cpu().numpy()].tobytes()
+        # scatter new Adam rows, read the whole state back through the ordinary accessor
+        new = torch.from_numpy(rng.standard_normal((300, 18)).astype(np.float32)).cuda()
+        ops.rows_scatter(D.ROWS_ADAM, ids, new)
+        ad = t.get_adam()[0].view(np.float32).reshape(n, 18)
+        assert ad[ids.cpu().numpy()].tobytes() == new.cpu().numpy().tobytes()
+        untouched = np.ones(n, dtype=bool); untouched[ids.cpu().numpy()] = False
+        assert not ad[untouched].any()
+        # masks: the formula of s2d_halo.hip in numpy
+        bounds = [0, 64, 128, 213]
+        m = ops.halo_masks(bounds, 4.0).cpu().numpy()
+        reach = np.float32(3.0) * np.maximum(sp[:, 2], sp[:, 3]) + np.float32(2.0) + np.float32(4.0)
+        want = np.zeros(n, dtype=np.int32)
+        for q in range(3):
+            want |= ((sp[:, 1] + reach >= np.float32(bounds[q])) & (sp[:, 1] - reach <= np.float32(bounds[q + 1]))).astype(np.int32) << q
+        assert (m == want).all() and (m != 0).all()
+        # combine: grads rows = partials of ranks 0, 1 (this one), 2 added in that order
+        t.forward(); t.backward()
+        g = t.get_grads().view(np.float32).reshape(n, 9).copy()
+        rows = torch.from_numpy(np.sort(rng.permutation(n)[:200]).astype(np.int32)).cuda()
+        recv = torch.from_numpy(rng.standard_normal((400, 9)).astype(np.float32)).cuda()
+        src = np.full((200, 3), -1, dtype=np.int32)
+        src[:, 1] = -2
+        src[:150, 0] = np.arange(150)                # rank 0 holds the first 150 rows
+        src[100:, 2] = 200 + np.arange(100)          # rank 2 holds the last 100
+        ops.grads_combine(rows, torch.from_numpy(src).cuda(), recv)
+        got = t.get_grads().view(np.float32).reshape(n, 9)
+        r, rc = rows.cpu().numpy(), recv.cpu().numpy()
+        want = g.copy()
+        for u, i in enumerate(r):
+            acc = None
+            for q in range(3):
+                s = src[u, q]
+                if s == -1:
+                    continue
+                v = g[i] if s == -2 else rc[s]
+                acc = v.copy() if acc is None else (acc + v).astype(np.float32)
+            want[i] = acc
+        assert got.tobytes() == want.tobytes()
+        # commit: only held splats are updated by Adam from here on
+        mask = torch.from_numpy((np.arange(n) % 2 == 0).astype(np.int32) * 2).cuda()  # rank 1 holds the even ids
+        ops.halo_commit(mask.contiguous(), 1)
+        before = t.get_splats().view(np.float32).reshape(n, 9).copy()
+        t.forward(); t.backward(); t.adam_step()
+        after = t.get_splats().view(np.float32).reshape(n, 9)
+        assert after[1::2].tobytes() == before[1::2].tobytes()
+        assert (after[0::2] != before[0::2]).any()
