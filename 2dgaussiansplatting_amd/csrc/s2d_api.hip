@@ -73,6 +73,9 @@ struct s2d_ctx {
     uint32_t* d_order_temp = nullptr;
     bool order_tiles = false;         // S2D_TILE_ORDER=1 in the environment: dispatch tiles longest list first.
                                       // Measured: 438 vs 444 it/s at 4096^2/1M, no change on a 1/8 slab -- off.
+    uint32_t* d_held_ids = nullptr;   // ... and their ascending id list, *d_held_count long, for the Adam kernel
+    uint32_t* d_held_count = nullptr;
+    uint32_t* d_held_work = nullptr;  // n words of scan workspace
     uint8_t* d_held = nullptr; // slab ownership: 1 = this rank holds (updates) the splat; nullptr = all (s2d_halo_commit)
     double* d_sqerr_trace = nullptr;
     int trace_cap = 1 << 16;
@@ -277,7 +280,8 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
     // rectangles (what the next forward needs), which saves a pass over the parameters per iteration.
     const bool fuse = c->lists_valid && c->rebin_interval > 1;
     if (fuse) c->check_seq++;
-    S2D_HIP(c, launch_adam(c->d_splats, c->d_adams, c->d_grads, c->d_held, c->n, c->g, c->beta1t, c->beta2t, c->lr,
+    S2D_HIP(c, launch_adam(c->d_splats, c->d_adams, c->d_grads, c->d_held_ids, c->d_held_count, c->n, c->g, c->beta1t, c->beta2t,
+                           c->lr,
                            (flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0, c->iterations, c->d_status,
                            fuse ? c->d_proj : nullptr, c->d_rects, c->check_seq, c->h_rebin_stamp, c->stream));
     if (fuse) S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
@@ -403,7 +407,7 @@ void s2d_destroy(s2d_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         void* ptrs[] = {c->d_splats, c->d_adams, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
-                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_order_buf, c->d_order_temp, c->d_sqerr_trace,
+                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work, c->d_order_buf, c->d_order_temp, c->d_sqerr_trace,
                         c->d_status, c->d_counters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -624,8 +628,14 @@ int s2d_halo_commit(s2d_ctx* c, const uint32_t* masks_device, int32_t rank, int3
     if (!c || !masks_device || rank < 0 || rank > 31) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
     const bool first = c->d_held == nullptr;
-    if (first) S2D_HIP(c, dev_alloc(&c->d_held, (size_t)c->n));
-    S2D_HIP(c, launch_halo_commit(masks_device, c->n, rank, c->d_held, c->stream));
+    if (first) {
+        S2D_HIP(c, dev_alloc(&c->d_held, (size_t)c->n));
+        S2D_HIP(c, dev_alloc(&c->d_held_ids, (size_t)c->n));
+        S2D_HIP(c, dev_alloc(&c->d_held_work, (size_t)c->n));
+        S2D_HIP(c, dev_alloc(&c->d_held_count, 4));
+    }
+    S2D_HIP(c, launch_halo_commit(masks_device, c->n, rank, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work,
+                                  c->d_scan_temp, c->stream));
     if (added || first) {
         // splats arrived: project the held ones and rebuild the tile lists before the next forward
         c->lists_valid = false;

@@ -177,7 +177,9 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
 // slab ownership (s2d_halo.hip): `held` == nullptr means every splat is held (single rank, or replicated state)
 hipError_t launch_halo_masks(const float* splats, const uint8_t* held, int n, int world, const int* row_bounds, float margin,
                              uint32_t* masks, hipStream_t stream);
-hipError_t launch_halo_commit(const uint32_t* masks, int n, int rank, uint8_t* held, hipStream_t stream);
+// also builds ids[0 .. *count_dev): the held splats in ascending order (scan_work: n words, scan_temp: scan_temp_words(n))
+hipError_t launch_halo_commit(const uint32_t* masks, int n, int rank, uint8_t* held, uint32_t* ids, uint32_t* count_dev,
+                              uint32_t* scan_work, uint32_t* scan_temp, hipStream_t stream);
 hipError_t launch_rows_gather(const float* base, int w, const int* ids, int count, int n, float* out, hipStream_t stream);
 hipError_t launch_rows_scatter(float* base, int w, const int* ids, int count, int n, const float* in, hipStream_t stream);
 hipError_t launch_grads_combine(float* grads, const int* rows, int n_rows, const int* src, int world, const float* recv,
@@ -190,7 +192,8 @@ hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double
 hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream);
 // proj != nullptr: also project the UPDATED splat for the next iteration and check it against rects[]
 // (what project_kernel mode 1 would do), raising status->rebin_needed.
-hipError_t launch_adam(float* splats, float* adams, float* grads, const uint8_t* held, int n, Geometry g, float beta1t, float beta2t,
+hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t* held_ids, const uint32_t* held_count, int n,
+                       Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
                        const TileRect* rects, int check_stamp, int* host_stamp, hipStream_t stream);
 hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, hipStream_t stream);

@@ -42,10 +42,21 @@ __global__ __launch_bounds__(256) void halo_masks_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void halo_commit_kernel(const uint32_t* __restrict__ masks, int n, int rank,
-                                                          uint8_t* __restrict__ held)
+                                                          uint8_t* __restrict__ held, uint32_t* __restrict__ flags)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) held[i] = (uint8_t)((masks[i] >> rank) & 1u);
+    if (i >= n) return;
+    const uint32_t h = (masks[i] >> rank) & 1u;
+    held[i] = (uint8_t)h;
+    flags[i] = h; // scanned into positions of the compact id list
+}
+
+// ids[pos[i]] = i for held splats: the ascending list the Adam kernel walks, so that its waves are full
+__global__ __launch_bounds__(256) void held_ids_kernel(const uint8_t* __restrict__ held, const uint32_t* __restrict__ pos, int n,
+                                                       uint32_t* __restrict__ ids)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && held[i]) ids[pos[i]] = (uint32_t)i;
 }
 
 // out[j][0..w) = base[ids[j]][0..w)
@@ -105,10 +116,16 @@ hipError_t launch_halo_masks(const float* splats, const uint8_t* held, int n, in
     return hipGetLastError();
 }
 
-hipError_t launch_halo_commit(const uint32_t* masks, int n, int rank, uint8_t* held, hipStream_t stream)
+hipError_t launch_halo_commit(const uint32_t* masks, int n, int rank, uint8_t* held, uint32_t* ids, uint32_t* count_dev,
+                              uint32_t* scan_work, uint32_t* scan_temp, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(halo_commit_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, masks, n, rank, held);
+    hipLaunchKernelGGL(halo_commit_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, masks, n, rank, held, scan_work);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    e = exclusive_scan_u32(scan_work, scan_work, n, scan_temp, count_dev, stream); // count_dev = number of held splats
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(held_ids_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, held, scan_work, n, ids);
     return hipGetLastError();
 }
 

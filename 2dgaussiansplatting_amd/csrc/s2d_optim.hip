@@ -31,17 +31,21 @@ __device__ __forceinline__ bool finite_f32(float x) { return (f32_bits(x) & 0x7f
 // iteration's forward) and to check it against the rectangle its tile lists were built from, so that the next
 // iteration needs no separate projection pass over the parameters.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, float* __restrict__ adams,
-                                                   float* __restrict__ grads, const uint8_t* __restrict__ held, int n,
-                                                   Geometry g, float beta1t,
+                                                   float* __restrict__ grads, const uint32_t* __restrict__ held_ids,
+                                                   const uint32_t* __restrict__ held_count, int n, Geometry g,
+                                                   float beta1t,
                                                    float beta2t, float lr, int optimize_opacity, int iteration,
                                                    DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
                                                    const TileRect* __restrict__ rects, int check_stamp,
                                                    int* __restrict__ host_stamp)
 {
     const int W = g.W, H = g.H;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (held && !held[i]) return; // slab ownership: updated by the ranks that hold it (s2d_halo.hip)
+    if (held_ids) { // slab ownership (s2d_halo.hip): only the splats this rank holds, from their compact list
+        if ((uint32_t)i >= *held_count) return;
+        i = (int)held_ids[i];
+    }
     float* sp = splats + (size_t)i * 9;
     float* ad = adams + (size_t)i * 18;
     float* gr = grads + (size_t)i * 9;
@@ -146,13 +150,13 @@ hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, 
     return hipGetLastError();
 }
 
-hipError_t launch_adam(float* splats, float* adams, float* grads, const uint8_t* held, int n, Geometry g, float beta1t,
-                       float beta2t,
+hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t* held_ids, const uint32_t* held_count,
+                       int n, Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
                        const TileRect* rects, int check_stamp, int* host_stamp, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, held, n, g, beta1t,
+    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, held_ids, held_count, n, g, beta1t,
                        beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp);
     return hipGetLastError();
 }
