@@ -147,6 +147,7 @@ class Trainer:
         cfg.rebin_interval = int(rebin_interval)
         cfg.rebin_margin = float(rebin_margin)
         cfg.stream = stream
+        self.stream = stream  # HIP stream handle the context works on; None: a stream the library owns
         h = C.c_void_p()
         rc = self.L.s2d_create(C.byref(cfg), C.byref(h))
         self._h = h

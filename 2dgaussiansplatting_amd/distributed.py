@@ -26,7 +26,8 @@ def slab_rows(height, rank, world, tile=16):
 
 
 class SlabStep:
-    """One training iteration of one rank."""
+    """One training iteration of one rank.  The collective and the backend must work on the same stream (bench.py
+    creates the Trainer on torch's current stream), or the caller must synchronise between them."""
 
     def __init__(self, backend, grads, dist=None):
         self.backend = backend
@@ -72,20 +73,40 @@ _ROW_WIDTH = {ROWS_GRADS: 9, ROWS_SPLATS: 9, ROWS_ADAM: 18}
 
 
 class HipHaloOps:
-    """The row operations of HaloStep on the HIP Trainer: torch tensors in, C-ABI calls with their device pointers."""
+    """The row operations of HaloStep on the HIP Trainer: torch tensors in, C-ABI calls with their device pointers.
+
+    The library's kernels and torch's (index building, the collective) touch the same buffers, so they must be
+    ordered: create the Trainer on torch's current stream (`Trainer(..., stream=torch.cuda.current_stream().cuda_stream)`
+    on a non-default stream, as bench.py does) and everything is stream-ordered for free.  If the Trainer works on
+    another stream (e.g. the one the library creates when none is given) every call here synchronises both sides
+    instead -- correct, but it stalls the host; meant for small tests."""
 
     def __init__(self, trainer, n, device):
         import torch
         self.torch, self.t, self.n, self.device = torch, trainer, n, device
+        cur = torch.cuda.current_stream().cuda_stream
+        self.shared_stream = trainer.stream is not None and trainer.stream != 0 and trainer.stream == cur
+
+    def _enter(self):  # torch-produced inputs must be complete before the library's stream reads them
+        if not self.shared_stream:
+            self.torch.cuda.current_stream().synchronize()
+
+    def _exit(self):   # ... and the library's results before torch reads them
+        if not self.shared_stream:
+            self.t.synchronize()
 
     def halo_masks(self, bounds, margin):
         m = self.torch.empty(self.n, dtype=self.torch.int32, device=self.device)
+        self._enter()
         self.t.halo_masks(list(bounds), float(margin), m.data_ptr())
+        self._exit()
         return m
 
     def halo_commit(self, mask, rank, added=True):
         assert mask.dtype == self.torch.int32 and mask.is_contiguous() and mask.numel() == self.n
+        self._enter()
         self.t.halo_commit(mask.data_ptr(), rank, 1 if added else 0)
+        self._exit()
 
     def rows_gather(self, what, ids, out=None):
         k = ids.numel()
@@ -93,7 +114,9 @@ class HipHaloOps:
             out = self.torch.empty((k, _ROW_WIDTH[what]), dtype=self.torch.float32, device=self.device)
         assert ids.dtype == self.torch.int32 and ids.is_contiguous() and out.is_contiguous()
         if k:
+            self._enter()
             self.t.rows_gather(what, ids.data_ptr(), k, out.data_ptr())
+            self._exit()
         return out
 
     def rows_scatter(self, what, ids, values):
@@ -101,13 +124,17 @@ class HipHaloOps:
         assert ids.dtype == self.torch.int32 and ids.is_contiguous() and values.is_contiguous()
         assert values.dtype == self.torch.float32 and values.numel() == k * _ROW_WIDTH[what]
         if k:
+            self._enter()
             self.t.rows_scatter(what, ids.data_ptr(), k, values.data_ptr())
+            self._exit()
 
     def grads_combine(self, rows, src, recv):
         k = rows.numel()
         assert rows.dtype == self.torch.int32 and src.dtype == self.torch.int32 and src.is_contiguous() and recv.is_contiguous()
         if k:
+            self._enter()
             self.t.grads_combine(rows.data_ptr(), k, src.data_ptr(), src.shape[1], recv.data_ptr())
+            self._exit()
 
 
 def _all_to_all_rows(dist, recv, send, recv_rows, send_rows):

@@ -769,8 +769,10 @@ def _run_ranks(world, W, H, n, steps, make_step, tgt=None):
 
     def body(rank, dist):
         r0, r1 = D.slab_rows(H, rank, world)
+        stream = torch.cuda.Stream()      # one stream per rank, shared by torch and the library (as in bench.py)
+        torch.cuda.set_stream(stream)     # thread-local
         grads = torch.zeros(n * 9, dtype=torch.float32, device="cuda")
-        with S2D.Trainer(W, H, n, row_begin=r0, row_end=r1, deterministic=True) as t:
+        with S2D.Trainer(W, H, n, row_begin=r0, row_end=r1, deterministic=True, stream=stream.cuda_stream) as t:
             t.bind_grads(grads.data_ptr())
             if tgt is None:
                 t.set_target_synthetic()

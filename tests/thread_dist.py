@@ -66,8 +66,9 @@ class _RankView:
         self.g.bar.wait()
 
     def all_reduce(self, t, op=_ReduceOp.SUM):
-        self._sync(t)
-        self.g.slots[self.rank] = t.clone()
+        c = t.clone()
+        self._sync(c)  # ranks may work on different streams: complete before another thread reads it
+        self.g.slots[self.rank] = c
         self.g.bar.wait()
         acc = self.g.slots[0].clone()
         for q in range(1, self.g.world):  # fixed order: every rank computes the same bits
