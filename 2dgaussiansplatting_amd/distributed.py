@@ -13,7 +13,7 @@ GPUs, gloo in the CPU tests -- and every rank applies the identical Adam step, s
 without ever exchanging parameters or framebuffers.
 
 `backend` is anything with forward() / backward() / adam_step(): the HIP Trainer bound to a torch gradient
-tensor in bench.py, or the oracle-backed stand-in of tests/test_distributed_gloo.py.
+tensor in bench.py, or the oracle-backed stand-in of tests/test_distributed_cpu.py.
 """
 
 
