@@ -148,6 +148,40 @@ def _all_to_all_rows(dist, recv, send, recv_rows, send_rows):
         dist.all_to_all_single(recv, send, recv_rows, send_rows)
 
 
+def all_to_all_selftest(dist, device):
+    """The collective pattern HaloStep relies on, on tiny tensors: all_to_all_single with UNEVEN row counts, zero-size
+    segments for non-neighbours, float32 and int32 payloads, plus the equal-split int64 count exchange.  Returns the
+    same verdict on every rank (an all-reduce of the local results), so callers can fall back together."""
+    import torch
+    ok = 1
+    try:
+        w, r = dist.get_world_size(), dist.get_rank()
+        near = [p for p in range(w) if p != r and abs(p - r) == 1]
+        send_rows = [(p + 1) if p in near else 0 for p in range(w)]   # rank r sends p+1 rows to neighbour p
+        recv_rows = [(r + 1) if p in near else 0 for p in range(w)]   # ... and so receives r+1 rows from each
+        for dtype in (torch.float32, torch.int32):
+            send = torch.cat([torch.full((k, 9), r * 100 + p, dtype=dtype, device=device) for p, k in enumerate(send_rows)])
+            recv = torch.full((sum(recv_rows), 9), -1, dtype=dtype, device=device)
+            _all_to_all_rows(dist, recv, send, recv_rows, send_rows)
+            want = torch.cat([torch.full((k, 9), p * 100 + r, dtype=dtype, device=device) for p, k in enumerate(recv_rows)])
+            ok &= int(torch.equal(recv, want))
+        cnt_out = torch.arange(w, dtype=torch.int64) + 10 * r
+        cnt_in = torch.empty_like(cnt_out)
+        if dist.get_backend() == "gloo":
+            dist.all_to_all_single(cnt_in, cnt_out)
+        else:
+            co, ci = cnt_out.to(device), cnt_in.to(device)
+            dist.all_to_all_single(ci, co)
+            cnt_in = ci.cpu()
+        ok &= int(cnt_in.tolist() == [r + 10 * p for p in range(w)])
+    except Exception:  # noqa: BLE001 - any failure means "do not use this path"
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int64)
+    f = flag if dist.get_backend() == "gloo" else flag.to(device)
+    dist.all_reduce(f, op=dist.ReduceOp.MIN)
+    return int(f.cpu().item()) == 1
+
+
 class HaloStep:
     """One training iteration of one rank under slab ownership.  `backend`: forward() / backward() / adam_step();
     `ops`: HipHaloOps or an equivalent (tests use an oracle-backed one)."""

@@ -227,3 +227,22 @@ def test_gloo_slab_ownership_matches_single_process(tmp_path, world, interval, m
     want = o.splats.view(np.float32).reshape(n, 9)
     np.testing.assert_allclose(full, want, rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(sq / (o.H * o.W * 3), mses, rtol=1e-6)
+
+
+def _selftest_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ok = D.all_to_all_selftest(dist, "cpu")
+        if rank == 0:
+            np.save(out, np.array([int(ok)]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_all_to_all_selftest_passes_on_gloo(tmp_path, world):
+    out = str(tmp_path / "ok.npy")
+    mp.spawn(_selftest_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    assert np.load(out)[0] == 1

@@ -7,7 +7,7 @@ import torch
 
 
 class _ReduceOp:
-    SUM, MAX = "sum", "max"
+    SUM, MAX, MIN = "sum", "max", "min"
 
 
 class ThreadDist:
@@ -72,7 +72,12 @@ class _RankView:
         self.g.bar.wait()
         acc = self.g.slots[0].clone()
         for q in range(1, self.g.world):  # fixed order: every rank computes the same bits
-            acc = torch.maximum(acc, self.g.slots[q]) if op == _ReduceOp.MAX else acc + self.g.slots[q]
+            if op == _ReduceOp.MAX:
+                acc = torch.maximum(acc, self.g.slots[q])
+            elif op == _ReduceOp.MIN:
+                acc = torch.minimum(acc, self.g.slots[q])
+            else:
+                acc = acc + self.g.slots[q]
         self._sync(acc)
         self.g.bar.wait()
         t.copy_(acc)
