@@ -910,3 +910,20 @@ def test_row_level_abi_calls_against_numpy():
         after = t.get_splats().view(np.float32).reshape(n, 9)
         assert after[1::2].tobytes() == before[1::2].tobytes()
         assert (after[0::2] != before[0::2]).any()
+
+
+def test_tile_dispatch_order_switch_changes_nothing(monkeypatch):
+    """S2D_TILE_ORDER=1 (tiles dispatched longest list first) is a scheduling choice only: same framebuffer, same
+    deterministic gradients, same MSE."""
+    tgt = mini_target()
+    res = []
+    for order in ("0", "1"):
+        monkeypatch.setenv("S2D_TILE_ORDER", order)
+        with S2D.Trainer(tgt.shape[1], tgt.shape[0], 3000, deterministic=True) as t:
+            t.set_target(tgt)
+            t.init()
+            t.step(3)
+            t.forward(); t.backward()
+            res.append((t.get_image().tobytes(), t.get_grads().tobytes(), t.mse()))
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    assert abs(res[0][2] - res[1][2]) <= 1e-12 * res[0][2]   # per-tile sums are added in tile order either way
