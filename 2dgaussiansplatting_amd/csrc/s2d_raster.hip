@@ -95,11 +95,12 @@ __device__ __forceinline__ void store_pixel(void* base, size_t i, float4 c)
 // A pair of fp32 values -- (vx,vy), (mx,my), the (r,g) colour channels, the two covariance dot products.  The blend
 // and gradient arithmetic below is written on such pairs with every product and sum in the reference's order.
 // Default: a plain struct whose operators are two scalar VALU instructions each.  Measured on MI355X
-// (tools/microbench/valu_rates.hip, profiles/r01/valu_rates.txt): a v_pk_{mul,add,fma}_f32 occupies a SIMD four
-// times as long as a v_{mul,add,fma}_f32, i.e. packed fp32 runs at HALF the per-component rate of scalar fp32 on
-// gfx950, so the pairs are deliberately NOT register-pair vectors and the build passes -fno-slp-vectorize to stop
-// LLVM from re-packing them.  -DS2D_PACKED_F32=1 selects the ext_vector_type form (v_pk_*_f32) for comparison;
-// both round each component exactly like the scalar instruction (no contraction: -ffp-contract=off).
+// (tools/microbench/valu_rates.hip, profiles/r01/valu_rates.txt): a v_pk_{mul,add,fma}_f32 occupies a SIMD for
+// ~4.3 cycles, a v_{mul,add,fma}_f32 for ~2.4 -- two components per instruction buy nothing on gfx950, and the
+// register-pair assembly the packed form needs makes these kernels slower (395 vs 413 it/s at the time).  So the
+// pairs are deliberately NOT register-pair vectors and the build passes -fno-slp-vectorize to stop LLVM from
+// re-packing them.  -DS2D_PACKED_F32=1 selects the ext_vector_type form (v_pk_*_f32) for comparison; both round
+// each component exactly like the scalar instruction (no contraction: -ffp-contract=off).
 #ifndef S2D_PACKED_F32
 #define S2D_PACKED_F32 0
 #endif
