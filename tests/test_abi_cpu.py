@@ -80,6 +80,17 @@ def test_create_rejects_bad_configs(lib):
     assert lib.s2d_forward(None) == 1 and lib.s2d_step(None, 1, 0, None) == 1
 
 
+def test_slab_ownership_calls_reject_bad_arguments(lib):
+    """s2d_halo_* / s2d_rows_* / s2d_grads_combine check their arguments before any device work."""
+    buf = (C.c_uint32 * 4)()
+    rows = (C.c_int32 * 3)(0, 16, 32)
+    assert lib.s2d_halo_masks(None, 2, rows, C.c_float(8.0), buf) == 1
+    assert lib.s2d_halo_commit(None, buf, 0, 1) == 1
+    assert lib.s2d_rows_gather(None, S2D.ROWS_SPLATS, buf, 1, buf) == 1
+    assert lib.s2d_rows_scatter(None, S2D.ROWS_ADAM, buf, 1, buf) == 1
+    assert lib.s2d_grads_combine(None, buf, 1, buf, 2, buf) == 1
+
+
 def _gpu_present():
     return os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK)
 
