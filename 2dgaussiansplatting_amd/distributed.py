@@ -59,7 +59,7 @@ def reduce_sqerr(sqerr, dist=None):
 # Rank q HOLDS splat i while [pos.y - reach - margin, pos.y + reach + margin] meets its rows (reach = 3*max(sx,sy)+2).
 # Invariants kept by HaloStep:
 #   (1) every rank whose rows a splat touches holds it (the margin is sized for Adam's worst-case step, see
-#       __init__, and hold sets are refreshed every `rehalo_interval` = 32 iterations; a splat that
+#       __init__, and hold sets are refreshed every `rehalo_interval` = 64 iterations; a splat that
 #       arrives already touching the receiver's rows raises);
 #   (2) all holders of a splat have bit-identical parameters and Adam state: they add the holders' partial
 #       gradients in ascending rank order (ops.grads_combine) and run the same Adam kernel;
@@ -186,7 +186,7 @@ class HaloStep:
     """One training iteration of one rank under slab ownership.  `backend`: forward() / backward() / adam_step();
     `ops`: HipHaloOps or an equivalent (tests use an oracle-backed one)."""
 
-    def __init__(self, backend, ops, dist, rank, world, height, rehalo_interval=32, margin_rows=None, lr=0.05):
+    def __init__(self, backend, ops, dist, rank, world, height, rehalo_interval=64, margin_rows=None, lr=0.05):
         import torch
         self.torch = torch
         self.backend, self.ops, self.dist = backend, ops, dist
@@ -196,7 +196,7 @@ class HaloStep:
         self.interval = int(rehalo_interval)
         # Adam moves a parameter by lr*|m^|/sqrt(v^) <= 2.35*lr per step for beta = (0.9, 0.99)
         # ((1-b1)/sqrt(1-b2) / sqrt(1 - b1^2/b2)); pos.y moves by that and reach = 3*max(sx,sy)+2 by three times
-        # that: the margin must outlast one refresh interval in the worst case (16.5 rows at 32 iterations)
+        # that: the margin must outlast one refresh interval in the worst case (33 rows at 64 iterations)
         self.margin = float(margin_rows) if margin_rows is not None else max(8.0, 1.1 * 2.35 * 4.0 * lr * self.interval)
         self.it = 0
         self.handed_over = 0  # splats whose state this rank received or sent since the start (diagnostic)

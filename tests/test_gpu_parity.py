@@ -834,7 +834,7 @@ def test_slab_ownership_default_margin_at_size():
     """Default refresh interval and margin on a workload with thousands of boundary splats: bit-identical to the
     replicated scheme on the same four slabs (both add the slabs' partials in rank order; a rank that does not hold
     a splat contributes an exact 0 there), and the MSE trace of the single-context run."""
-    W, H, n, steps = 1024, 768, 60000, 36
+    W, H, n, steps = 1024, 768, 60000, 72   # one refresh (every 64 iterations) besides the one at construction
     halo = _run_ranks(4, W, H, n, steps, lambda D, t, g, dist, r, w, hh: D.HaloStep(
         t, D.HipHaloOps(t, n, "cuda"), dist, r, w, hh))
     dense = _run_ranks(4, W, H, n, steps, lambda D, t, g, dist, r, w, hh: D.SlabStep(t, g, dist))

@@ -52,7 +52,8 @@ def main():
                 t.init()
                 dist = Loopback() if world > 1 else None
                 if scheme == "halo":
-                    step = D.HaloStep(t, D.HipHaloOps(t, n, "cuda"), dist, rank, world, H)
+                    step = D.HaloStep(t, D.HipHaloOps(t, n, "cuda"), dist, rank, world, H,
+                                          rehalo_interval=int(os.environ.get("S2D_REHALO", "32")))
                 else:
                     step = D.SlabStep(t, grads, dist)
                 for _ in range(16):
