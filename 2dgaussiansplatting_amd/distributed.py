@@ -184,7 +184,8 @@ def all_to_all_selftest(dist, device):
 
 class HaloStep:
     """One training iteration of one rank under slab ownership.  `backend`: forward() / backward() / adam_step();
-    `ops`: HipHaloOps or an equivalent (tests use an oracle-backed one)."""
+    `ops`: HipHaloOps or an equivalent (tests use an oracle-backed one).  Construct it while every rank still has the
+    same, complete set of splats (after init / set_splats / a checkpoint load on all ranks)."""
 
     def __init__(self, backend, ops, dist, rank, world, height, rehalo_interval=64, margin_rows=None, lr=0.05):
         import torch
@@ -302,15 +303,22 @@ class HaloStep:
         got = t.empty((sum(in_rows), 29), dtype=t.int32, device=dev)
         _all_to_all_rows(dist, got, pay, in_rows, out_rows)
         mask = t.where(held & (((new >> r) & 1) == 1), new, t.zeros_like(new))  # 0 for splats dropped or never held
+        late = 0
         if got.shape[0]:
             rid = got[:, 0].contiguous()
             sp = got[:, 2:11].contiguous().view(t.float32)
             ad = got[:, 11:29].contiguous().view(t.float32)
             reach = 3.0 * t.maximum(sp[:, 2], sp[:, 3]) + 2.0
             touching = (sp[:, 1] + reach >= float(self.r0)) & (sp[:, 1] - reach <= float(self.r1))
-            if bool(touching.any().item()):
-                raise RuntimeError("slab ownership: %d splat(s) reached the rows of rank %d before being handed over; "
-                                   "raise margin_rows or lower rehalo_interval" % (int(touching.sum().item()), r))
+            late = int(touching.sum().item())
+        # invariant (1) broken anywhere is fatal everywhere: agree on it, so that no rank is left in a collective
+        worst = t.tensor([late], dtype=t.int64)
+        w = worst if dist.get_backend() == "gloo" else worst.to(dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        if int(w.cpu().item()) > 0:
+            raise RuntimeError("slab ownership: a splat reached the rows of a rank before its state was handed over "
+                               "(%d on rank %d); raise margin_rows or lower rehalo_interval" % (late, r))
+        if got.shape[0]:
             ops.rows_scatter(ROWS_SPLATS, rid, sp)
             ops.rows_scatter(ROWS_ADAM, rid, ad)
             mask[rid.long()] = got[:, 1]

@@ -246,3 +246,12 @@ def test_all_to_all_selftest_passes_on_gloo(tmp_path, world):
     out = str(tmp_path / "ok.npy")
     mp.spawn(_selftest_worker, args=(world, _free_port(), out), nprocs=world, join=True)
     assert np.load(out)[0] == 1
+
+
+def test_gloo_slab_ownership_without_margin_fails_on_every_rank(tmp_path):
+    """With no halo margin a splat reaches a neighbour's rows before it is handed over: every rank must raise (none
+    may be left waiting in a collective)."""
+    out = str(tmp_path / "res")
+    with pytest.raises(Exception) as ei:
+        mp.spawn(_halo_worker, args=(2, _free_port(), 12, 600, 3, 0.0, out), nprocs=2, join=True)
+    assert "handed over" in str(ei.value)
