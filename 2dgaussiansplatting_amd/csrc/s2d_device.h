@@ -73,7 +73,10 @@ __device__ __forceinline__ ProjRec pack_proj(const Projected& p)
     rec.q0 = make_float4(p.pos_x, p.pos_y, p.a, p.b);
     rec.q1 = make_float4(p.d, p.col_r, p.col_g, p.col_b);
     rec.q2 = make_float4(p.opacity, as_f(p.begY), as_f(p.endY), p.cosT);
-    rec.q3 = make_float4(p.sinT, p.sx, p.sy, p.hx);
+    // what the backward pass needs of the scales, once per splat instead of once per (tile, splat): 1/sx^3, 1/sy^3
+    // (main.cpp:657-662, :677-678) and (sx^2 - sy^2)/(sx^2 sy^2) (main.cpp:680-685), in the reference's operation order
+    const float sx2 = p.sx * p.sx, sy2 = p.sy * p.sy;
+    rec.q3 = make_float4(p.sinT, 1.0f / (sx2 * p.sx), 1.0f / (sy2 * p.sy), (sx2 - sy2) / (sx2 * p.sy * p.sy));
     return rec;
 }
 

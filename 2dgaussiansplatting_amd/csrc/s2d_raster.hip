@@ -555,15 +555,14 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
                 const uint32_t idx = list[base + se];
                 const ProjRec* r = proj + idx;
                 const float4 q0 = r->q0, q1 = r->q1, q2 = r->q2;
-                const float4 q3 = r->q3;
-                const float cosT = q2.w, sinT = q3.x, sx = q3.y, sy = q3.z;
-                const float sx2 = sx * sx, sy2 = sy * sy;
+                const float4 q3 = r->q3; // sin, 1/sx^3, 1/sy^3, (sx^2-sy^2)/(sx^2 sy^2): divided once per splat (pack_proj)
+                const float cosT = q2.w, sinT = q3.x;
                 const float cc = cosT * cosT, ss = sinT * sinT, sc2 = 2.0f * sinT * cosT;
                 s_q0[se] = q0;
                 s_q1[se] = make_float4(q0.w, q1.x, q1.y, q1.z);
-                s_q2[se] = make_float4(q1.w, q2.x, (sx2 - sy2) / (sx2 * sy * sy), sinT * cosT);
+                s_q2[se] = make_float4(q1.w, q2.x, q3.w, sinT * cosT);
                 s_e0[se] = make_float4(cc, ss, sc2, -sc2);
-                s_e1[se] = make_float4(ss, cc, 1.0f / (sx2 * sx), 1.0f / (sy2 * sy));
+                s_e1[se] = make_float4(ss, cc, q3.y, q3.z);
                 s_idx[par][se] = idx;
             }
         }
