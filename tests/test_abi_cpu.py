@@ -7,7 +7,6 @@ import re
 import subprocess
 import tempfile
 
-import numpy as np
 import pytest
 
 import oracle_lib as O

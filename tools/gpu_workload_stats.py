@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """GPU-box tool: pair/lane statistics of one iteration at a given size (diagnostic counters on)."""
-import importlib, os, sys, time
+import importlib, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
