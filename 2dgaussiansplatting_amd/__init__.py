@@ -54,7 +54,7 @@ class _Stats(C.Structure):
                 ("bwd_active", C.c_uint64), ("fwd_staged", C.c_uint64), ("bwd_staged", C.c_uint64),
                 ("fwd_wave_execs", C.c_uint64), ("bwd_wave_execs", C.c_uint64), ("bwd_lane_hist", C.c_uint64 * 65),
                 ("iterations", C.c_int32), ("first_nonfinite_iteration", C.c_int32),
-                ("fwd_staged_hit", C.c_uint64), ("fwd_rows_hit", C.c_uint64)]
+                ("fwd_staged_hit", C.c_uint64), ("fwd_rows_hit", C.c_uint64), ("phase_cycles", C.c_uint64 * 16)]
 
 
 # every symbol include/splat2d.h declares
@@ -63,6 +63,7 @@ ABI_SYMBOLS = [
     "s2d_init_splats", "s2d_set_splats", "s2d_get_splats", "s2d_set_adam", "s2d_get_adam", "s2d_forward",
     "s2d_get_image", "s2d_backward", "s2d_get_grads", "s2d_adam_step", "s2d_step", "s2d_get_mse",
     "s2d_bind_grads_device", "s2d_grads_device_ptr", "s2d_get_sqerr_trace", "s2d_synchronize", "s2d_get_stats",
+    "s2d_get_rebuild_count",
     "s2d_last_error", "s2d_test_sincos", "s2d_test_sort_pairs", "s2d_test_exclusive_scan",
     "s2d_debug_get_tile_lists",
     "s2d_halo_masks", "s2d_halo_commit", "s2d_rows_gather", "s2d_rows_scatter", "s2d_grads_combine",
@@ -106,6 +107,7 @@ def load_library(path=None):
     L.s2d_get_sqerr_trace.argtypes = [vp, i32, i32, vp]
     L.s2d_synchronize.argtypes = [vp]
     L.s2d_get_stats.argtypes = [vp, C.POINTER(_Stats)]
+    L.s2d_get_rebuild_count.argtypes = [vp, vp]
     L.s2d_last_error.argtypes = [vp]
     L.s2d_last_error.restype = C.c_char_p
     L.s2d_test_sincos.argtypes = [i32, vp, i32, vp, vp]
@@ -294,7 +296,14 @@ class Trainer:
         self._ck(self.L.s2d_get_stats(self._h, C.byref(s)))
         out = {k: getattr(s, k) for k, _ in _Stats._fields_}
         out["bwd_lane_hist"] = list(s.bwd_lane_hist)
+        out["phase_cycles"] = list(s.phase_cycles)
         return out
+
+    def rebuild_count(self):
+        """Times the tile lists were rebuilt so far (host-side counter: no device synchronisation)."""
+        v = C.c_uint64()
+        self._ck(self.L.s2d_get_rebuild_count(self._h, C.byref(v)))
+        return v.value
 
     def tile_lists(self):
         st = self.stats()

@@ -69,10 +69,6 @@ struct s2d_ctx {
     bool half_images = false;
     size_t pixel_bytes = sizeof(float4);
     double* d_tile_sqerr = nullptr;
-    uint32_t* d_order_buf = nullptr;  // 4 x num_tiles: keys/vals double buffer for the longest-first tile order
-    uint32_t* d_order_temp = nullptr;
-    bool order_tiles = false;         // S2D_TILE_ORDER=1 in the environment: dispatch tiles longest list first.
-                                      // Measured: 438 vs 444 it/s at 4096^2/1M, no change on a 1/8 slab -- off.
     uint32_t* d_held_ids = nullptr;   // ... and their ascending id list, *d_held_count long, for the Adam kernel
     uint32_t* d_held_count = nullptr;
     uint32_t* d_held_work = nullptr;  // n words of scan workspace
@@ -88,6 +84,8 @@ struct s2d_ctx {
     // host-side state of the reference's main()
     float beta1t = 1.0f, beta2t = 1.0f; // main.cpp:274-275
     int iterations = 0;                 // main.cpp:278
+    float good_beta1t = 1.0f, good_beta2t = 1.0f; // the three above at the last point known to be finite
+    int good_iterations = 0;
     bool have_target = false;
     bool have_forward = false;
     bool have_backward = false;
@@ -177,7 +175,9 @@ int rebuild_lists(s2d_ctx* c)
     S2D_HIP(c, exclusive_scan_u32(c->d_counts, c->d_offsets, n, c->d_scan_temp, c->d_total, c->stream));
     S2D_HIP(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
-    const uint64_t total = *c->h_total;
+    const uint64_t total = *c->h_total; // saturates at 0xFFFFFFFF instead of wrapping (scan_top_kernel)
+    if (total >= 0xFFFF0000ull)
+        return fail(c, S2D_E_NOMEM, "tile lists need more than 2^32 - 65536 (tile, splat) pairs");
     int rc = ensure_pair_capacity(c, total);
     if (rc != S2D_OK) return rc;
     S2D_HIP(c, launch_emit_pairs(c->d_rects, c->d_offsets, n, c->g, c->d_keys[0], c->d_vals[0],
@@ -188,15 +188,6 @@ int rebuild_lists(s2d_ctx* c)
     S2D_HIP(c, launch_tile_offsets(k_out, (uint32_t)total, c->g.num_tiles, c->d_tile_off, c->stream));
     c->d_list = v_out;
     c->pairs = total;
-    c->g.tile_order = nullptr;
-    if (c->order_tiles && c->g.num_tiles > 1) {
-        const size_t nt = (size_t)c->g.num_tiles;
-        uint32_t *ok = nullptr, *ov = nullptr;
-        S2D_HIP(c, launch_tile_order_keys(c->d_tile_off, c->g.num_tiles, c->d_order_buf, c->d_order_buf + nt, c->stream));
-        S2D_HIP(c, sort_pairs_u32(c->d_order_buf, c->d_order_buf + nt, c->d_order_buf + 2 * nt, c->d_order_buf + 3 * nt,
-                                  (int64_t)nt, 16, c->d_order_temp, &ok, &ov, c->stream));
-        c->g.tile_order = ov;
-    }
     c->rebins++;
     c->lists_valid = true;
     c->since_rebin = 0;
@@ -204,11 +195,11 @@ int rebuild_lists(s2d_ctx* c)
 }
 
 // Forward pass on lists that are known to cover the current parameters.
-int launch_forward(s2d_ctx* c, const int* abort_flag)
+int launch_forward(s2d_ctx* c, bool optimistic)
 {
-    const int abort_stamp = c->check_seq;
+    const int abort_stamp = optimistic ? c->check_seq : 0;
     S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->half_images, c->d_wave_masks,
-                                     c->g, abort_flag, abort_stamp, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr,
+                                     c->g, c->d_status, abort_stamp, c->iterations, c->d_counters, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) != 0,
                                      c->stream));
     return S2D_OK;
 }
@@ -235,7 +226,7 @@ int queue_forward(s2d_ctx* c)
             S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
             c->proj_fresh = true;
         }
-        if (int rc = launch_forward(c, &c->d_status->rebin_needed)) return rc;
+        if (int rc = launch_forward(c, true)) return rc;
         S2D_HIP(c, hipEventSynchronize(c->ev_flag)); // the checking kernel, not the forward kernel
         rebuild = *(volatile int*)c->h_rebin_stamp == c->check_seq;
     }
@@ -245,7 +236,7 @@ int queue_forward(s2d_ctx* c)
         if (int rc = rebuild_lists(c)) return rc;
         c->proj_fresh = true;
         c->check_seq++; // the new lists cover the current parameters: a stamp that asked for them matches nothing now
-        if (int rc = launch_forward(c, nullptr)) return rc;
+        if (int rc = launch_forward(c, false)) return rc;
     }
     c->have_forward = true;
     c->have_backward = false;
@@ -264,9 +255,9 @@ int queue_backward(s2d_ctx* c, bool need_opacity_grad)
     S2D_HIP(c, launch_raster_backward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->half_images,
                                       c->d_wave_masks, c->d_grads,
                                       c->d_tile_sqerr, c->g, need_opacity_grad, c->deterministic ? &dg : nullptr,
-                                      (c->cfg.flags & S2D_CFG_COUNT_PAIRS) ? c->d_counters : nullptr, c->stream));
+                                      c->d_status, c->iterations, c->d_counters, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) != 0, c->stream));
     S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->d_tile_sqerr + c->g.num_tiles,
-                                     c->stream));
+                                     c->d_status, c->iterations, c->stream));
     c->last_sqerr_slot = slot;
     c->have_backward = true;
     return S2D_OK;
@@ -293,13 +284,35 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
     return S2D_OK;
 }
 
+// New parameters (init / set_splats): a non-finite event of the old ones no longer stops the queue.
+int reset_status(s2d_ctx* c)
+{
+    static const DeviceStatus fresh{0, INT_MAX, 0, 0}; // rebin_needed 0 matches no check (sequence numbers start at 1)
+    S2D_HIP(c, hipMemcpyAsync(c->d_status, &fresh, sizeof(DeviceStatus), hipMemcpyHostToDevice, c->stream));
+    return S2D_OK;
+}
+
 int check_status(s2d_ctx* c)
 {
     S2D_HIP(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(DeviceStatus), hipMemcpyDeviceToHost, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
-    if (c->h_status->nonfinite)
-        return fail(c, S2D_E_NONFINITE, "non-finite parameter after iteration %d (the reference abort()s, main.cpp:752-785)",
-                    c->h_status->first_nonfinite_iter);
+    if (c->h_status->nonfinite) {
+        // The kernels queued behind the failing Adam step did nothing: put the host-side counters back to where the
+        // device stopped (that step's update is the last thing that happened, as at the reference's abort()).
+        const int k = c->h_status->first_nonfinite_iter;
+        if (k >= c->good_iterations && k < c->iterations) {
+            float b1 = c->good_beta1t, b2 = c->good_beta2t;
+            for (int i = c->good_iterations; i <= k; i++) { b1 *= kAdamBeta1; b2 *= kAdamBeta2; } // main.cpp:718-719
+            c->beta1t = b1;
+            c->beta2t = b2;
+            c->iterations = k + 1;
+            c->have_forward = c->have_backward = false;
+        }
+        return fail(c, S2D_E_NONFINITE, "non-finite parameter after iteration %d (the reference abort()s, main.cpp:752-785)", k);
+    }
+    c->good_beta1t = c->beta1t;
+    c->good_beta2t = c->beta2t;
+    c->good_iterations = c->iterations;
     return S2D_OK;
 }
 
@@ -364,9 +377,6 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, dev_alloc(&c->d_scan_temp, scan_temp_words((int64_t)n)));
     S2D_HIP(c, dev_alloc(&c->d_total, 4));
     S2D_HIP(c, dev_alloc(&c->d_tile_off, (size_t)g.num_tiles + 1));
-    S2D_HIP(c, dev_alloc(&c->d_order_buf, (size_t)g.num_tiles * 4));
-    S2D_HIP(c, dev_alloc(&c->d_order_temp, sort_temp_words((int64_t)g.num_tiles)));
-    if (const char* e = getenv("S2D_TILE_ORDER")) c->order_tiles = e[0] != '0';
     c->deterministic = (cfg->flags & S2D_CFG_DETERMINISTIC) != 0;
     c->half_images = (cfg->flags & S2D_CFG_FP16_IMAGES) != 0;
     c->pixel_bytes = c->half_images ? 8 : sizeof(float4);
@@ -407,7 +417,7 @@ void s2d_destroy(s2d_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         void* ptrs[] = {c->d_splats, c->d_adams, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
-                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work, c->d_order_buf, c->d_order_temp, c->d_sqerr_trace,
+                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work, c->d_sqerr_trace,
                         c->d_status, c->d_counters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
@@ -460,9 +470,10 @@ int s2d_init_splats(s2d_ctx* c)
     if (int rc = use_device(c)) return rc;
     S2D_HIP(c, launch_init_splats(c->d_splats, c->d_adams, c->n, c->g.W, c->g.H, c->stream));
     if (c->n > 0) S2D_HIP(c, hipMemsetAsync(c->d_grads, 0, (size_t)c->n * 9 * sizeof(float), c->stream));
-    c->beta1t = 1.0f; // main.cpp:283-284
-    c->beta2t = 1.0f;
-    c->iterations = 0; // main.cpp:281
+    if (int rc = reset_status(c)) return rc;
+    c->beta1t = c->good_beta1t = 1.0f; // main.cpp:283-284
+    c->beta2t = c->good_beta2t = 1.0f;
+    c->iterations = c->good_iterations = 0; // main.cpp:281
     c->lists_valid = false;
     c->proj_fresh = false;
     c->have_forward = c->have_backward = false;
@@ -474,6 +485,7 @@ int s2d_set_splats(s2d_ctx* c, const s2d_splat* splats)
     if (!c || (!splats && c->n)) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
     S2D_HIP(c, hipMemcpyAsync(c->d_splats, splats, (size_t)c->n * sizeof(s2d_splat), hipMemcpyHostToDevice, c->stream));
+    if (int rc = reset_status(c)) return rc;
     S2D_HIP(c, hipStreamSynchronize(c->stream));
     c->lists_valid = false;
     c->proj_fresh = false;
@@ -496,9 +508,9 @@ int s2d_set_adam(s2d_ctx* c, const s2d_splat_adam* adams, float beta1t, float be
     if (int rc = use_device(c)) return rc;
     S2D_HIP(c, hipMemcpyAsync(c->d_adams, adams, (size_t)c->n * sizeof(s2d_splat_adam), hipMemcpyHostToDevice, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
-    c->beta1t = beta1t;
-    c->beta2t = beta2t;
-    c->iterations = iterations;
+    c->beta1t = c->good_beta1t = beta1t;
+    c->beta2t = c->good_beta2t = beta2t;
+    c->iterations = c->good_iterations = iterations;
     return S2D_OK;
 }
 
@@ -572,6 +584,7 @@ int s2d_step(s2d_ctx* c, int32_t iters, uint32_t flags, double* mse_out)
     if (!c || iters < 0) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
     const double norm = mse_norm(c);
+    const int call_first_iter = c->iterations;
     int done = 0;
     while (done < iters) {
         const int chunk = std::min(iters - done, c->trace_cap);
@@ -587,7 +600,14 @@ int s2d_step(s2d_ctx* c, int32_t iters, uint32_t flags, double* mse_out)
         }
         done += chunk;
     }
-    return check_status(c);
+    const int rc = check_status(c);
+    if (rc == S2D_E_NONFINITE && mse_out) {
+        // The reference abort()s right after the Adam step of that iteration (main.cpp:752-785): its trace ends with
+        // that iteration's line.  The kernels of the later iterations queued here did nothing; their entries are NaN.
+        const int last_valid = c->h_status->first_nonfinite_iter - call_first_iter;
+        for (int k = std::max(last_valid + 1, 0); k < iters; k++) mse_out[k] = std::nan("");
+    }
+    return rc;
 }
 
 int s2d_get_mse(s2d_ctx* c, double* mse)
@@ -734,8 +754,16 @@ int s2d_get_stats(s2d_ctx* c, s2d_stats* out)
     for (int k = 0; k < 65; k++) out->bwd_lane_hist[k] = pc.bwd_lane_hist[k];
     out->fwd_staged_hit = pc.fwd_staged_hit;
     out->fwd_rows_hit = pc.fwd_rows_hit;
+    for (int k = 0; k < 16; k++) out->phase_cycles[k] = pc.phase_cycles[k];
     out->iterations = c->iterations;
     out->first_nonfinite_iteration = c->h_status->nonfinite ? c->h_status->first_nonfinite_iter : -1;
+    return S2D_OK;
+}
+
+int s2d_get_rebuild_count(const s2d_ctx* c, uint64_t* rebuilds)
+{
+    if (!c || !rebuilds) return S2D_E_INVALID;
+    *rebuilds = c->rebins;
     return S2D_OK;
 }
 

@@ -82,23 +82,6 @@ __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __res
     for (int t = prev + 1; t <= cur; t++) tile_off[t] = p;
 }
 
-__global__ __launch_bounds__(256) void tile_order_keys_kernel(const uint32_t* __restrict__ tile_off, int num_tiles,
-                                                              uint32_t* __restrict__ keys, uint32_t* __restrict__ vals)
-{
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= num_tiles) return;
-    const uint32_t len = tile_off[t + 1] - tile_off[t];
-    keys[t] = 0xFFFFu - (len < 0xFFFFu ? len : 0xFFFFu);
-    vals[t] = (uint32_t)t;
-}
-
-hipError_t launch_tile_order_keys(const uint32_t* tile_off, int num_tiles, uint32_t* keys, uint32_t* vals, hipStream_t stream)
-{
-    if (num_tiles <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tile_order_keys_kernel, dim3((num_tiles + 255) / 256), dim3(256), 0, stream, tile_off, num_tiles, keys, vals);
-    return hipGetLastError();
-}
-
 hipError_t launch_project(const float* splats, const uint8_t* held, int n, Geometry g, float margin, int mode, ProjRec* proj,
                           TileRect* rects, uint32_t* counts, DeviceStatus* status, int check_stamp, int* host_stamp,
                           hipStream_t stream)

@@ -33,9 +33,6 @@ struct Geometry {
     int trow0;          // row_begin / 16: first global tile row of the slab
     int tiles_y;        // tile rows in the slab
     int num_tiles;      // tiles_x * tiles_y
-    // Dispatch order of the raster kernels: block b works on tile tile_order[b] (nullptr: tile b).  Rebuilt with the
-    // tile lists, longest list first, so that the last round of workgroups is made of short tiles (speed only).
-    const uint32_t* tile_order;
 };
 
 struct PairCounters {
@@ -44,6 +41,10 @@ struct PairCounters {
     unsigned long long bwd_lane_hist[65]; // executed (wave, entry) pairs by number of active lanes
     unsigned long long fwd_staged_hit;    // staged entries with at least one pixel of the tile inside their ranges
     unsigned long long fwd_rows_hit;      // (staged entry, tile row) pairs with a non-empty column range
+    // -DS2D_PHASE_TIMING builds only: shader-clock cycles summed over waves.  [0..3] forward: staging, barrier after
+    // staging, blend loop, barrier after the loop; [6] whole kernel, [7] executed (wave, entry) pairs.  [8..12] backward:
+    // staging, barrier, blend loop, barrier, flush; [14] whole kernel, [15] executed (wave, entry) pairs.
+    unsigned long long phase_cycles[16];
 };
 
 // Device-resident status word(s), written by kernels, read by the host at synchronisation points.
@@ -138,10 +139,6 @@ hipError_t sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, 
                           int key_bits, uint32_t* temp, uint32_t** keys_out, uint32_t** vals_out,
                           hipStream_t stream);
 
-// keys[t] = 0xFFFF - min(list length of tile t, 0xFFFF), vals[t] = t: sorting by these 16-bit keys orders the tiles
-// longest list first (s2d_binning.hip)
-hipError_t launch_tile_order_keys(const uint32_t* tile_off, int num_tiles, uint32_t* keys, uint32_t* vals, hipStream_t stream);
-
 // binning (s2d_binning.hip)
 // Projects every splat; mode 0: also writes rects[] (inflated by `margin` pixels) and counts[];
 // mode 1: checks that the exact rectangle lies inside rects[] and raises status->rebin_needed otherwise.
@@ -154,11 +151,12 @@ hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, 
                                uint32_t* tile_off, hipStream_t stream);
 
 // raster (s2d_raster.hip)
-// abort_flag (device, may be null): when it reads non-zero at kernel start the launch does nothing -- the lists it
-// would walk are stale and the host rebuilds them and launches again.
+// abort_stamp != 0: when status->rebin_needed equals it at kernel start the launch does nothing -- the lists it would
+// walk are stale and the host rebuilds them and launches again.  Every kernel of an iteration does nothing once a
+// parameter went non-finite in an earlier iteration (status->first_nonfinite_iter < iteration).
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
-                                 bool half_images, unsigned long long* wave_masks, Geometry g, const int* abort_flag,
-                                 int abort_stamp, PairCounters* counters, hipStream_t stream);
+                                 bool half_images, unsigned long long* wave_masks, Geometry g, const DeviceStatus* status,
+                                 int abort_stamp, int iteration, PairCounters* counters, bool count, hipStream_t stream);
 // Deterministic gradient accumulation (S2D_CFG_DETERMINISTIC): instead of float atomics every tile stores its
 // partial gradient of a splat into the slot offsets[splat] + (position of the tile in the splat's emission
 // rectangle), stamped with the iteration; a gather kernel then sums each splat's stamped slots in slot order.
@@ -174,8 +172,8 @@ struct DetGather {
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
                                   const void* image0, const void* image_ref, bool half_images,
                                   const unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
-                                  bool need_opacity_grad, const DetGather* dg, PairCounters* counters,
-                                  hipStream_t stream);
+                                  bool need_opacity_grad, const DetGather* dg, const DeviceStatus* status, int iteration,
+                                  PairCounters* counters, bool count, hipStream_t stream);
 // Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
 // slab ownership (s2d_halo.hip): `held` == nullptr means every splat is held (single rank, or replicated state)
 hipError_t launch_halo_masks(const float* splats, const uint8_t* held, int n, int world, const int* row_bounds, float margin,
@@ -189,7 +187,8 @@ hipError_t launch_grads_combine(float* grads, const int* rows, int n_rows, const
                                 int n, hipStream_t stream);
 // scratch: kSqerrScratchDoubles doubles, zero before the first launch
 constexpr int kSqerrScratchDoubles = 64 + 1;
-hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, double* scratch, hipStream_t stream);
+hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, double* scratch,
+                                 const DeviceStatus* status, int iteration, hipStream_t stream);
 
 // optimiser / init (s2d_optim.hip)
 hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream);

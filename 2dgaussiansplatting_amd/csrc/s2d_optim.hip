@@ -42,6 +42,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
     const int W = g.W, H = g.H;
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // The reference abort()s at the first non-finite parameter (main.cpp:752-785): later iterations do nothing.
+    // (Strictly earlier: blocks of the detecting launch itself, which stores `iteration`, must all finish their work.)
+    if (status->first_nonfinite_iter < iteration) return;
     if (held_ids) { // slab ownership (s2d_halo.hip): only the splats this rank holds, from their compact list
         if ((uint32_t)i >= *held_count) return;
         i = (int)held_ids[i];
@@ -84,7 +87,14 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
         // 3-sigma circle (plus the 1-pixel skirt) stays clear of the slab has an empty exact rectangle, which every
         // binned rectangle covers: skip its projection (7/8 of the splats at 8 ranks).  NaNs fall through.
         const float reach = 3.0f * fmaxf(v[2], v[3]) + 2.0f;
-        if (v[1] + reach < (float)g.row_begin || v[1] - reach > (float)g.row_end) return;
+        if (v[1] + reach < (float)g.row_begin || v[1] - reach > (float)g.row_end) {
+            // ... but the re-used tile lists may still name it (it was inside when they were built, and one Adam step
+            // can carry it out by any distance for a large training_rate or loaded moments): leave a record with
+            // an empty row range (begY > endY) behind, so that the raster kernels see no footprint instead of its
+            // stale one.
+            proj[i].q2 = make_float4(v[8], as_f(1), as_f(0), 0.0f);
+            return;
+        }
         Splat s;
         s.pos_x = v[0]; s.pos_y = v[1]; s.sx = v[2]; s.sy = v[3]; s.rot = v[4];
         s.col_r = v[5]; s.col_g = v[6]; s.col_b = v[7]; s.opacity = v[8];

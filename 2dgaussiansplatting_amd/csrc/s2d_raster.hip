@@ -1,8 +1,7 @@
 // s2d_raster.hip -- tile-binned forward rasteriser and analytic backward pass.
 //
-// One 256-thread workgroup (4 wave64) per 16x16 image tile, one thread per pixel.  Each wave owns a
-// WX x (64/WX) pixel block of the tile (kWaveW = 16: four 16x4 strips; kWaveW = 8: four 8x8 blocks), with
-// lane = WX * (row in block) + (column in block).  A tile walks its splat list (ascending splat index ==
+// One 256-thread workgroup (4 wave64) per 16x16 image tile, one thread per pixel.  Each wave owns an 8x8 pixel
+// block of the tile, lane = 8 * (row in block) + (column in block).  A tile walks its splat list (ascending splat index ==
 // the reference's blend order, main.cpp:419/:552) in batches of 64 entries staged in LDS:
 //   * 4 threads per entry load the 64-byte projected record and evaluate the reference's exact per-row
 //     column range (solve_quadratic + int truncation, main.cpp:498-509) for 4 tile rows each, producing one
@@ -32,30 +31,13 @@ namespace s2d {
 constexpr int B = kRasterBatch;
 static_assert(B == 64, "lane l of a wave holds the mask of batch entry l");
 
-#ifndef S2D_WAVE_W
-#define S2D_WAVE_W 8
-#endif
-constexpr int kWaveW = S2D_WAVE_W;     // pixel columns per wave block: 16 (16x4 strips) or 8 (8x8 blocks)
-constexpr int kWaveH = 64 / kWaveW;    // pixel rows per wave block
+constexpr int kWaveW = 8;              // pixel columns per wave block (8x8 blocks: measured better than 16x4 strips,
+constexpr int kWaveH = 64 / kWaveW;    // profiles/r01: 34 vs 37 executed entries per wave, 36 vs 33 active lanes)
 constexpr int kWavesX = kTile / kWaveW;
-static_assert(kWaveW == 16 || kWaveW == 8, "wave block is 16x4 or 8x8");
 
-// Block -> tile.  Default: dispatch order (blocks are dealt round-robin over the 8 XCDs, which balances the
-// uneven per-tile work best).  -DS2D_XCD_REMAP gives each XCD a contiguous run of tiles instead, so that
-// neighbouring tiles, which share most of their splat records, hit the same L2: measured 1.7 % SLOWER at
-// 4096^2 / 1 M (352 vs 358 it/s) because these kernels are VALU-issue-bound, not L2-bound, and the contiguous
-// runs balance worse.  Kept as a switch for memory-bound configurations.  Speed only, never correctness.
-__device__ __forceinline__ int tile_of_block(int bid, const Geometry& g)
-{
-#ifdef S2D_XCD_REMAP
-    const int per = (g.num_tiles + 7) >> 3;
-    const int t = (bid & 7) * per + (bid >> 3);
-    return t < g.num_tiles ? t : -1;
-#else
-    if (bid >= g.num_tiles) return -1;
-    return g.tile_order ? (int)g.tile_order[bid] : bid;
-#endif
-}
+// Block -> tile: dispatch order.  (An XCD-contiguous remap and a longest-list-first order were measured slower,
+// profiles/r01/README.md: these kernels are VALU-issue-bound, not L2-bound.)
+__device__ __forceinline__ int tile_of_block(int bid, const Geometry& g) { return bid < g.num_tiles ? bid : -1; }
 
 __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src_lane)
 {
@@ -63,6 +45,17 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
     const uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), src_lane);
     return ((unsigned long long)hi << 32) | lo;
 }
+
+// Diagnostic build only (-DS2D_PHASE_TIMING, tools/build_timing_lib.py; never the shipped library): every wave adds
+// the shader-clock cycles it spends in each phase of the batch loop to PairCounters::phase_cycles, which tells
+// where the waves of the raster kernels wait (staging latency, barriers, the blend loop, the flush).
+#ifdef S2D_PHASE_TIMING
+#define S2D_T(var) const long long var = (long long)clock64()
+#define S2D_TACC(slot, a, b) ph[slot] += (unsigned long long)((b) - (a))
+#else
+#define S2D_T(var)
+#define S2D_TACC(slot, a, b)
+#endif
 
 // Framebuffer / target pixel in HBM: RGBA32F (the reference's Image2DRGBA32, 16 B) or, with S2D_CFG_FP16_IMAGES,
 // four IEEE halves (8 B, round-to-nearest-even on store).  Arithmetic is fp32 either way.
@@ -94,23 +87,10 @@ __device__ __forceinline__ void store_pixel(void* base, size_t i, float4 c)
 
 // A pair of fp32 values -- (vx,vy), (mx,my), the (r,g) colour channels, the two covariance dot products.  The blend
 // and gradient arithmetic below is written on such pairs with every product and sum in the reference's order.
-// Default: a plain struct whose operators are two scalar VALU instructions each.  Measured on MI355X
-// (tools/microbench/valu_rates.hip, profiles/r01/valu_rates.txt): a v_pk_{mul,add,fma}_f32 occupies a SIMD for
-// ~4.3 cycles, a v_{mul,add,fma}_f32 for ~2.4 -- two components per instruction buy nothing on gfx950, and the
-// register-pair assembly the packed form needs makes these kernels slower (395 vs 413 it/s at the time).  So the
-// pairs are deliberately NOT register-pair vectors and the build passes -fno-slp-vectorize to stop LLVM from
-// re-packing them.  -DS2D_PACKED_F32=1 selects the ext_vector_type form (v_pk_*_f32) for comparison; both round
-// each component exactly like the scalar instruction (no contraction: -ffp-contract=off).
-#ifndef S2D_PACKED_F32
-#define S2D_PACKED_F32 0
-#endif
-#ifndef S2D_LDS_REDUCE
-#define S2D_LDS_REDUCE 1 // backward: wave-wide gradient sums through an LDS transpose (1) or the swap/DPP butterfly (0)
-#endif
-#if S2D_PACKED_F32
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-#else
+// A plain struct whose operators are two scalar VALU instructions each: on gfx950 a v_pk_{mul,add,fma}_f32 occupies a
+// SIMD for ~4.3 cycles, a v_{mul,add,fma}_f32 for ~2.4 (tools/microbench/valu_rates.hip, profiles/r01/valu_rates.txt),
+// so packed fp32 buys nothing and the register-pair assembly it needs costs (395 vs 413 it/s, profiles/r01/v8_*);
+// the build passes -fno-slp-vectorize so LLVM does not re-pack these.
 struct f2 {
     float x, y;
 };
@@ -119,17 +99,9 @@ __device__ __forceinline__ f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y -
 __device__ __forceinline__ f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
 __device__ __forceinline__ f2 operator*(f2 a, float b) { return f2{a.x * b, a.y * b}; }
 __device__ __forceinline__ f2 operator*(float a, f2 b) { return f2{a * b.x, a * b.y}; }
-__device__ __forceinline__ f2 operator+(f2 a, float b) { return f2{a.x + b, a.y + b}; }
-__device__ __forceinline__ f2 operator+(float a, f2 b) { return f2{a + b.x, a + b.y}; }
-__device__ __forceinline__ f2 operator-(f2 a, float b) { return f2{a.x - b, a.y - b}; }
-__device__ __forceinline__ f2 operator-(float a, f2 b) { return f2{a - b.x, a - b.y}; }
 __device__ __forceinline__ f2 operator-(f2 a) { return f2{-a.x, -a.y}; }
 __device__ __forceinline__ f2& operator+=(f2& a, f2 b) { a = a + b; return a; }
-__device__ __forceinline__ f2& operator-=(f2& a, f2 b) { a = a - b; return a; }
-__device__ __forceinline__ f2& operator*=(f2& a, f2 b) { a = a * b; return a; }
-__device__ __forceinline__ f2& operator*=(f2& a, float b) { a = a * b; return a; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return f2{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y)}; }
-#endif
 __device__ __forceinline__ f2 mk2(float a, float b)
 {
     f2 r;
@@ -158,20 +130,14 @@ __device__ __forceinline__ int stage_masks(uint32_t* s_mask32, int se, int sub, 
         rm[k] = 0;
         if (yy < row_end) rm[k] = row_mask16(q0.x, q0.y, q0.z, q0.w, q1.x, begY, endY, yy, x_tile, W);
     }
-    if (kWaveW == 16) {
-        // wave = sub; lane = 16 * k + column
-        s_mask32[(sub * B + se) * 2 + 0] = rm[0] | (rm[1] << 16);
-        s_mask32[(sub * B + se) * 2 + 1] = rm[2] | (rm[3] << 16);
-    } else {
-        // waves (wy, 0) and (wy, 1) with wy = sub >> 1; rows (sub & 1) * 4 + k of the 8x8 block; lane = 8 * row + column
-        const int wy = sub >> 1, half = sub & 1;
+    // waves (wy, 0) and (wy, 1) with wy = sub >> 1; rows (sub & 1) * 4 + k of the 8x8 block; lane = 8 * row + column
+    const int wy = sub >> 1, half = sub & 1;
 #pragma unroll
-        for (int wx = 0; wx < 2; wx++) {
-            const int sh = 8 * wx;
-            const uint32_t word = ((rm[0] >> sh) & 0xFFu) | (((rm[1] >> sh) & 0xFFu) << 8) |
-                                  (((rm[2] >> sh) & 0xFFu) << 16) | (((rm[3] >> sh) & 0xFFu) << 24);
-            s_mask32[((wy * 2 + wx) * B + se) * 2 + half] = word;
-        }
+    for (int wx = 0; wx < 2; wx++) {
+        const int sh = 8 * wx;
+        const uint32_t word = ((rm[0] >> sh) & 0xFFu) | (((rm[1] >> sh) & 0xFFu) << 8) |
+                              (((rm[2] >> sh) & 0xFFu) << 16) | (((rm[3] >> sh) & 0xFFu) << 24);
+        s_mask32[((wy * 2 + wx) * B + se) * 2 + half] = word;
     }
     return (rm[0] != 0u) + (rm[1] != 0u) + (rm[2] != 0u) + (rm[3] != 0u); // non-empty rows (diagnostic counter)
 }
@@ -185,8 +151,8 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                                                              const ProjRec* __restrict__ proj,
                                                              void* __restrict__ image0,
                                                              unsigned long long* __restrict__ wave_masks, Geometry g,
-                                                             const int* __restrict__ abort_flag, int abort_stamp,
-                                                             PairCounters* __restrict__ counters)
+                                                             const DeviceStatus* __restrict__ status, int abort_stamp,
+                                                             int iteration, PairCounters* __restrict__ counters)
 {
     // per-entry record, three 16-B rows at one LDS address (one address register for the blend loop's reads):
     //   [0] pos.x, pos.y, a, b   [1] b, d, col_r, col_g   [2] col_b, opacity, -, -
@@ -197,7 +163,9 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
     // Optimistic launch: the host queues this kernel before it has seen the containment flag the previous Adam
     // (or projection) kernel produced.  If some splat left its binned rectangle the lists are stale: do nothing;
     // the host rebuilds them and launches again.  The flag is final before this kernel starts (stream order).
-    if (abort_flag != nullptr && *abort_flag == abort_stamp) return;
+    // abort_stamp 0: lists known to be current.  A parameter that went non-finite in an EARLIER iteration stops the
+    // run where the reference abort()s (main.cpp:752-785): every later kernel of the queue does nothing.
+    if ((abort_stamp != 0 && status->rebin_needed == abort_stamp) || status->first_nonfinite_iter < iteration) return;
     const int tile = tile_of_block(blockIdx.x, g);
     if (tile < 0) return;
     const int tx = tile % g.tiles_x;
@@ -217,11 +185,17 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
     // single scalar unit -- not the SIMDs -- then bounds the loop; measured, profiles/r01/valu_rates.txt.)
     unsigned long long alive_mask = __ballot(inside);
     unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0, n_rows_hit = 0, n_staged_hit = 0;
+#ifdef S2D_PHASE_TIMING
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long n_exec_t = 0;
+#endif
+    S2D_T(tk0);
 
     const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
     const int se = tid >> 2, sub = tid & 3;
     for (uint32_t base = beg; base < end; base += B) {
         const int cnt = (int)min((uint32_t)B, end - base);
+        S2D_T(t0);
         if (se < cnt) {
             const ProjRec* r = proj + list[base + se];
             const float4 q0 = r->q0, q1 = r->q1, q2 = r->q2;
@@ -238,7 +212,9 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                 s_rec[se][2] = make_float4(q1.w, q2.x, 0.0f, 0.0f);
             }
         }
+        S2D_T(t1);
         __syncthreads();
+        S2D_T(t2);
         // keep the lane masks for the backward pass, which walks exactly these batches (32 B per staged pair)
         if (se < cnt) wave_masks[(size_t)(base + se) * 4 + sub] = s_mask[sub * B + se];
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
@@ -253,6 +229,9 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                 const unsigned long long act = wm & alive_mask; // visited (main.cpp:511-514) and not cut off (:520)
                 if (act == 0ull) continue;
                 if (COUNT) n_exec += (lane == 0);
+#ifdef S2D_PHASE_TIMING
+                n_exec_t++;
+#endif
                 // Branch-free body: lanes outside `act` run the same instructions with alpha forced to 0, which
                 // makes c += (T*c)*0 and T *= 1 exact no-ops.  The scalar mask itself is the select predicate.
                 const float4 q0 = s_rec[e][0], q1 = s_rec[e][1], q2 = s_rec[e][2];
@@ -270,8 +249,23 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                 if (COUNT) n_act += (act >> lane) & 1ull;
             }
         }
-        if (!__syncthreads_or(alive_mask != 0ull ? 1 : 0)) break;
+        S2D_T(t3);
+        const int any_alive = __syncthreads_or(alive_mask != 0ull ? 1 : 0);
+        S2D_T(t4);
+        S2D_TACC(0, t0, t1);
+        S2D_TACC(1, t1, t2);
+        S2D_TACC(2, t2, t3);
+        S2D_TACC(3, t3, t4);
+        if (!any_alive) break;
     }
+#ifdef S2D_PHASE_TIMING
+    if (lane == 0) {
+        S2D_T(tk1);
+        for (int k = 0; k < 4; k++) atomicAdd(&counters->phase_cycles[k], ph[k]);
+        atomicAdd(&counters->phase_cycles[6], (unsigned long long)(tk1 - tk0));
+        atomicAdd(&counters->phase_cycles[7], n_exec_t);
+    }
+#endif
     if (inside) store_pixel<HALF>(image0, (size_t)y * g.W + x, make_float4(crg.x, crg.y, cb, 1.0f)); // .w reset, main.cpp:543-546
     if (COUNT) {
         atomicAdd(&counters->fwd_visited, n_vis);
@@ -284,87 +278,10 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Wave-wide sums of the nine partial gradients.
-//
-// Eight of them go through a PACKED butterfly: at every level two registers are folded into one, so the
-// number of live registers halves together with the number of lanes per value:
-//   level 32: v_permlane32_swap(x, y) makes x = [x.lo | y.lo], y = [x.hi | y.hi]; x + y holds the half-folded x
-//             in lanes 0-31 and the half-folded y in lanes 32-63           (8 -> 4 registers: 4 swaps + 4 adds)
-//   level 16: v_permlane16_swap the same way on rows of 16 lanes           (4 -> 2 registers: 2 swaps + 2 adds)
-//   level  8: two bank-masked DPP adds (row_ror:8) write the folded first register into lanes 0-7 and the
-//             folded second register into lanes 8-15 of every row          (2 -> 1 register: 2 adds)
-//   levels 4, 2, 1: row_half_mirror, quad_perm xor 1, quad_perm xor 2      (3 adds)
-// 17 VALU instructions instead of 48; afterwards every lane of the 8-lane group g = lane >> 3 holds the total
-// of value bitrev3(g).  The ninth value (the opacity gradient) takes the plain six-step DPP chain to lane 63,
-// interleaved with the tail of the butterfly so that the DPP read-after-write wait states are mostly filled;
-// it is skipped when the caller does not need it.  All 64 lanes are active here (wave-uniform control flow).
-// ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void swap_fold32(float& x, float& y)
-{
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-__device__ __forceinline__ void swap_fold16(float& x, float& y)
-{
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-    x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
-template <bool NINTH>
-__device__ __forceinline__ float wave_sum8_packed(float a0, float a1, float a2, float a3, float a4, float a5, float a6,
-                                                  float a7, float& a8)
-{
-    swap_fold32(a0, a1); // a0 = [a0 | a1]
-    swap_fold32(a2, a3);
-    swap_fold32(a4, a5);
-    swap_fold32(a6, a7);
-    swap_fold16(a0, a2); // rows: a0, a2, a1, a3
-    swap_fold16(a4, a6); // rows: a4, a6, a5, a7
-    float d;
-    if (NINTH) {
-        asm volatile("s_nop 1\n"
-                     "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0x3\n"
-                     "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0xc\n"
-                     "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                     "s_nop 0\n"
-                     "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
-                     "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                     "s_nop 0\n"
-                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                     "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n"
-                     "s_nop 0\n"
-                     "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                     "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n"
-                     "s_nop 1\n"
-                     "v_add_f32_dpp %1, %1, %1 row_bcast:15 row_mask:0xa bank_mask:0xf\n"
-                     "s_nop 1\n"
-                     "v_add_f32_dpp %1, %1, %1 row_bcast:31 row_mask:0xc bank_mask:0xf\n"
-                     "s_nop 1\n"
-                     : "=&v"(d), "+v"(a8)
-                     : "v"(a0), "v"(a4));
-    } else {
-        asm volatile("s_nop 1\n"
-                     "v_add_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n"
-                     "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n"
-                     "s_nop 1\n"
-                     "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n"
-                     "s_nop 1\n"
-                     "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
-                     "s_nop 1\n"
-                     "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n"
-                     "s_nop 1\n"
-                     : "=&v"(d)
-                     : "v"(a0), "v"(a4));
-    }
-    return d;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// The same eight wave-wide sums through LDS (default, -DS2D_LDS_REDUCE=0 selects the butterfly above).
+// Wave-wide sums of eight of the nine partial gradients, through LDS.
 // On gfx950 a v_permlane*_swap occupies the SIMD for ~8.8 cycles and a DPP add for ~4.6 against 2.4 for a plain
-// v_add_f32 (tools/microbench/valu_rates.hip), so the butterfly costs ~90 SIMD cycles per (wave, entry) of a
-// VALU-bound kernel, while the LDS pipe idles.  Here every lane stores its 8 partials component-major into a
+// v_add_f32 (tools/microbench/valu_rates.hip), so a swap/DPP butterfly costs ~90 SIMD cycles per (wave, entry) of a
+// VALU-bound kernel (profiles/r01/v9_bench_lds_reduce.json), while the LDS pipe idles.  Here every lane stores its 8 partials component-major into a
 // wave-private scratch (element n = 64*c + lane), reads back elements 8*lane .. 8*lane+7 -- eight lanes' worth of
 // component lane>>3 -- with two 16-B reads, adds them pairwise (7 plain adds) and finishes inside its 8-lane
 // group with three DPP adds: ~31 SIMD cycles.  Afterwards every lane of group g = lane >> 3 holds the total of
@@ -466,13 +383,8 @@ struct DetSlots {
     uint32_t now;             // iteration + 1
 };
 
-#ifdef S2D_BWD_WAVES_PER_SIMD // A/B switch: cap the register budget so that this many waves fit a SIMD
-#define S2D_BWD_OCC __attribute__((amdgpu_waves_per_eu(S2D_BWD_WAVES_PER_SIMD, S2D_BWD_WAVES_PER_SIMD)))
-#else
-#define S2D_BWD_OCC
-#endif
 template <bool COUNT, bool NEED_OP, bool HALF, bool DET>
-__global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
+__global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
                                                               const uint32_t* __restrict__ list,
                                                               const ProjRec* __restrict__ proj,
                                                               const void* __restrict__ image0,
@@ -480,7 +392,8 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
                                                               const unsigned long long* __restrict__ wave_masks,
                                                               float* __restrict__ grads,
                                                               double* __restrict__ tile_sqerr, Geometry g,
-                                                              DetSlots det, PairCounters* __restrict__ counters)
+                                                              DetSlots det, const DeviceStatus* __restrict__ status,
+                                                              int iteration, PairCounters* __restrict__ counters)
 {
     __shared__ float4 s_q0[B]; // pos.x, pos.y, a, b
     __shared__ float4 s_q1[B]; // b, d, col_r, col_g
@@ -498,10 +411,9 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
     __shared__ float4 s_part[kPartWaves][B][3];
     __shared__ unsigned long long s_touched[4]; // bit e: wave w wrote slot e in this batch
     __shared__ double s_red[4];
-#if S2D_LDS_REDUCE
     __shared__ __attribute__((aligned(16))) float s_xpose[4][kRedDwords]; // wave-private transpose scratch
-#endif
 
+    if (status->first_nonfinite_iter < iteration) return; // the reference abort()ed in an earlier iteration
     const int tile = tile_of_block(blockIdx.x, g);
     if (tile < 0) return;
     const int tx = tile % g.tiles_x;
@@ -513,12 +425,7 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
     const int y = ty * kTile + ly;
     const bool inside = x < g.W && y < g.row_end;
     const f2 pxy = mk2((float)x + 0.5f, (float)y + 0.5f);
-    // after wave_sum8_packed the 8-lane group (lane >> 3) holds the total of record component bitrev3(lane >> 3)
-#if S2D_LDS_REDUCE
     const int part_slot = lane >> 3; // after wave_sum8_lds the 8-lane group holds the total of component lane >> 3
-#else
-    const int part_slot = ((lane >> 3) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 5) & 1);
-#endif
 
     float4 fin = make_float4(0.f, 0.f, 0.f, 0.f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
     if (inside) {
@@ -545,12 +452,18 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
     float cb = 0.0f, T = 1.0f;
     unsigned long long alive_mask = __ballot(inside); // wave-uniform, scalar registers (see the forward kernel)
     unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0;
+#ifdef S2D_PHASE_TIMING
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long n_exec_t = 0;
+#endif
+    S2D_T(tk0);
 
     const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
     const int se = tid >> 2, sub = tid & 3;
     int par = 0;
     for (uint32_t base = beg; base < end; base += B, par ^= 1) {
         const int cnt = (int)min((uint32_t)B, end - base);
+        S2D_T(t0);
         if (se < cnt) {
             // the forward pass of this iteration staged the same batch and left its lane masks behind
             s_mask[sub * B + se] = wave_masks[(size_t)(base + se) * 4 + sub];
@@ -569,7 +482,9 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
                 s_idx[par][se] = idx;
             }
         }
+        S2D_T(t1);
         __syncthreads();
+        S2D_T(t2);
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
         unsigned long long touched = 0ull;
         if (alive_mask != 0ull || COUNT) {
@@ -584,6 +499,9 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
                 if (act_mask == 0ull) continue;
                 touched |= 1ull << e;
                 if (COUNT) n_exec += (lane == 0);
+#ifdef S2D_PHASE_TIMING
+                n_exec_t++;
+#endif
                 // Lanes this splat does not visit (main.cpp:595-598) or whose pixel is already below the throughput
                 // cut-off (main.cpp:604) run the same instructions with alpha forced to 0: then c += T*c*0 and
                 // T *= 1 are exact no-ops and every gradient term below is a multiple of alpha, i.e. exactly 0 --
@@ -646,11 +564,7 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
                     alive_mask &= __ballot(!(T < kMinThroughput));
                 }
                 // order of the record: pos.xy, sx, sy, rot, color.rgb, opacity (main.cpp:85-93)
-#if S2D_LDS_REDUCE
                 const float tot = wave_sum8_lds<NEED_OP>(s_xpose[w], lane, g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
-#else
-                const float tot = wave_sum8_packed<NEED_OP>(g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
-#endif
                 float* part = reinterpret_cast<float*>(&s_part[DET ? w : 0][e][0]);
                 if (DET) {
                     if ((lane & 7) == 0) part[part_slot] = tot;
@@ -662,7 +576,9 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
             }
         }
         if (DET && lane == 0) s_touched[w] = touched;
+        S2D_T(t3);
         const int any = __syncthreads_or(alive_mask != 0ull ? 1 : 0);
+        S2D_T(t4);
         // one burst per (tile, splat): 9 consecutive floats -- float atomics into grads[idx], or (deterministic
         // mode) plain stores into this tile's own slot of the splat, summed later in a fixed order
         for (int i = tid; i < cnt * 9; i += 256) {
@@ -696,8 +612,22 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
                 atomicAdd(grads + (size_t)s_idx[par][e] * 9 + k, v);
             }
         }
+        S2D_T(t5);
+        S2D_TACC(0, t0, t1);
+        S2D_TACC(1, t1, t2);
+        S2D_TACC(2, t2, t3);
+        S2D_TACC(3, t3, t4);
+        S2D_TACC(4, t4, t5);
         if (!any) break;
     }
+#ifdef S2D_PHASE_TIMING
+    if (lane == 0) {
+        S2D_T(tk1);
+        for (int k = 0; k < 5; k++) atomicAdd(&counters->phase_cycles[8 + k], ph[k]);
+        atomicAdd(&counters->phase_cycles[14], (unsigned long long)(tk1 - tk0));
+        atomicAdd(&counters->phase_cycles[15], n_exec_t);
+    }
+#endif
     if (COUNT) {
         atomicAdd(&counters->bwd_visited, n_vis);
         atomicAdd(&counters->bwd_active, n_act);
@@ -705,11 +635,6 @@ __global__ __launch_bounds__(256) S2D_BWD_OCC void raster_backward_kernel(const 
         if (lane == 0) atomicAdd(&counters->bwd_wave_execs, n_exec);
     }
 }
-
-#ifndef S2D_PPL
-#define S2D_PPL 1 // pixels per lane: 1 = raster_*_kernel above, 2 = raster_*2_kernel (s2d_raster2.inc)
-#endif
-#include "s2d_raster2.inc"
 
 // Deterministic mode: gradient of splat i = sum of the partials its tiles stored this iteration, in emission
 // (tile row-major) order -- the same order whatever the dispatch order of the tiles was.
@@ -750,10 +675,12 @@ __device__ __forceinline__ double block_sum_256(double v, double* s)
 }
 
 __global__ __launch_bounds__(256) void sqerr_finalize_kernel(const double* __restrict__ tile_sqerr, int num_tiles,
-                                                             double* __restrict__ out, double* scratch)
+                                                             double* __restrict__ out, double* scratch,
+                                                             const DeviceStatus* __restrict__ status, int iteration)
 {
     __shared__ double s[4];
     __shared__ bool last;
+    if (status->first_nonfinite_iter < iteration) return;
     unsigned long long* ticket = reinterpret_cast<unsigned long long*>(scratch + kSqerrBlocks);
     const int chunk = (num_tiles + kSqerrBlocks - 1) / kSqerrBlocks;
     const int beg = blockIdx.x * chunk, end = min(beg + chunk, num_tiles);
@@ -786,21 +713,14 @@ __global__ __launch_bounds__(256) void sqerr_finalize_kernel(const double* __res
 static inline unsigned raster_grid(int num_tiles) { return (unsigned)(((num_tiles + 7) / 8) * 8); }
 
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
-                                 bool half_images, unsigned long long* wave_masks, Geometry g, const int* abort_flag,
-                                 int abort_stamp,
-                                 PairCounters* counters, hipStream_t stream)
+                                 bool half_images, unsigned long long* wave_masks, Geometry g, const DeviceStatus* status,
+                                 int abort_stamp, int iteration, PairCounters* counters, bool count, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
-#if S2D_PPL == 2
-    const dim3 grid(raster_grid(g.num_tiles)), block(kBlock2);
-#define S2D_LAUNCH_FWD(C, H) \
-    hipLaunchKernelGGL((raster_forward2_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, abort_flag, abort_stamp, counters)
-#else
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
 #define S2D_LAUNCH_FWD(C, H) \
-    hipLaunchKernelGGL((raster_forward_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, abort_flag, abort_stamp, counters)
-#endif
-    if (counters) {
+    hipLaunchKernelGGL((raster_forward_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, status, abort_stamp, iteration, counters)
+    if (count) {
         if (half_images) S2D_LAUNCH_FWD(true, true); else S2D_LAUNCH_FWD(true, false);
     } else {
         if (half_images) S2D_LAUNCH_FWD(false, true); else S2D_LAUNCH_FWD(false, false);
@@ -812,25 +732,19 @@ hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list,
 hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj,
                                   const void* image0, const void* image_ref, bool half_images,
                                   const unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
-                                  bool need_opacity_grad, const DetGather* dg, PairCounters* counters, hipStream_t stream)
+                                  bool need_opacity_grad, const DetGather* dg, const DeviceStatus* status, int iteration,
+                                  PairCounters* counters, bool count, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
     DetSlots det{nullptr, nullptr, nullptr, nullptr, 0u};
     if (dg) det = DetSlots{dg->rects, dg->offsets, dg->data, dg->stamp, dg->now};
-#if S2D_PPL == 2
-    const dim3 grid(raster_grid(g.num_tiles)), block(kBlock2);
-#define S2D_LAUNCH_BWD(C, O, H, D)                                                                                       \
-    hipLaunchKernelGGL((raster_backward2_kernel<C, O, H, D>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
-                       wave_masks, grads, tile_sqerr, g, det, counters)
-#else
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
 #define S2D_LAUNCH_BWD(C, O, H, D)                                                                                       \
     hipLaunchKernelGGL((raster_backward_kernel<C, O, H, D>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
-                       wave_masks, grads, tile_sqerr, g, det, counters)
-#endif
+                       wave_masks, grads, tile_sqerr, g, det, status, iteration, counters)
 #define S2D_LAUNCH_BWD_D(C, O, H) do { if (dg) S2D_LAUNCH_BWD(C, O, H, true); else S2D_LAUNCH_BWD(C, O, H, false); } while (0)
 #define S2D_LAUNCH_BWD_H(C, O) do { if (half_images) S2D_LAUNCH_BWD_D(C, O, true); else S2D_LAUNCH_BWD_D(C, O, false); } while (0)
-    if (counters) {
+    if (count) {
         if (need_opacity_grad) S2D_LAUNCH_BWD_H(true, true); else S2D_LAUNCH_BWD_H(true, false);
     } else {
         if (need_opacity_grad) S2D_LAUNCH_BWD_H(false, true); else S2D_LAUNCH_BWD_H(false, false);
@@ -844,9 +758,11 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
     return hipGetLastError();
 }
 
-hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, double* scratch, hipStream_t stream)
+hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, double* scratch,
+                                 const DeviceStatus* status, int iteration, hipStream_t stream)
 {
-    hipLaunchKernelGGL(sqerr_finalize_kernel, dim3(kSqerrBlocks), dim3(256), 0, stream, tile_sqerr, num_tiles, out, scratch);
+    hipLaunchKernelGGL(sqerr_finalize_kernel, dim3(kSqerrBlocks), dim3(256), 0, stream, tile_sqerr, num_tiles, out, scratch,
+                       status, iteration);
     return hipGetLastError();
 }
 

@@ -44,7 +44,8 @@ __device__ __forceinline__ uint32_t block_exclusive_scan_u32(uint32_t v, uint32_
 }
 
 // ---------------------------------------------------------------------------------------------------
-// exclusive scan: reduce per block -> scan block sums (one block) -> scan per block + base
+// exclusive scan: reduce per block -> scan block sums (one block) -> scan per block + base.
+// *total_dev saturates at 0xFFFFFFFF when the sum does not fit 32 bits (the prefixes are then meaningless).
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(const uint32_t* __restrict__ in, int64_t n,
                                                                  uint32_t* __restrict__ block_sums)
@@ -66,16 +67,30 @@ __global__ __launch_bounds__(kScanBlock) void scan_top_kernel(uint32_t* __restri
                                                               uint32_t* __restrict__ total_out)
 {
     __shared__ uint32_t s_wave[4];
+    __shared__ unsigned long long s_wide[kScanBlock / 64];
     uint32_t carry = 0;
+    unsigned long long wide = 0; // this thread's share of the grand total, carried in 64 bits
     for (int64_t base = 0; base < nb; base += kScanBlock) {
         int64_t i = base + threadIdx.x;
         uint32_t v = (i < nb) ? block_sums[i] : 0u;
+        wide += v;
         uint32_t tot;
         uint32_t ex = block_exclusive_scan_u32(v, &tot, s_wave);
         if (i < nb) block_sums[i] = carry + ex;
         carry += tot;
     }
-    if (threadIdx.x == 0 && total_out) *total_out = carry;
+    // The 32-bit prefix sums wrap silently when the grand total does not fit (tile lists of > 2^32 pairs: a few 10^4
+    // splats at the sx/sy clamp on a 4096^2 image).  Report a SATURATED total then, so the caller sees "too many"
+    // instead of a small wrapped number.
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wide += __shfl_down(wide, d, 64);
+    if ((threadIdx.x & 63) == 0) s_wide[threadIdx.x >> 6] = wide;
+    __syncthreads();
+    if (threadIdx.x == 0 && total_out) {
+        unsigned long long all = 0;
+        for (int k = 0; k < kScanBlock / 64; k++) all += s_wide[k];
+        *total_out = all > 0xFFFFFFFFull ? 0xFFFFFFFFu : carry;
+    }
 }
 
 // in and out may be the same array (each thread reads its items before it writes them)

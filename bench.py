@@ -3,12 +3,17 @@
 splatting on a 4096x4096 synthetic image with 1,000,000 Gaussians (BASELINE.json metric / configs[3]).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One process per GPU.  The image is split into N row slabs (whole tile rows); splats and Adam state are
-replicated; per iteration each rank rasterises its slab forward and backward, the N x 9 fp32 gradient
-array is all-reduced over RCCL/xGMI (the only exchange), and every rank applies the identical Adam step.
-The total work is fixed as N grows ("strong" scaling).  Prints ONE JSON line on rank 0.
+One process per GPU.  With N > 1 and no launcher environment (WORLD_SIZE unset) this process only SPAWNS the N
+ranks -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...`
+as a child, before anything here touches the GPU -- relays rank 0's JSON line and returns the child's exit code;
+started under torch.distributed.run it is one of the ranks.
+
+The image is split into N row slabs (whole tile rows).  --exchange halo (default for N > 1): slab OWNERSHIP -- a
+rank holds, lists and updates only the splats that can reach its rows and exchanges the gradient rows of splats
+held by more than one rank (one all_to_all over RCCL/xGMI per iteration).  --exchange dense: splats and Adam state
+replicated, the N x 9 fp32 gradient array all-reduced every iteration (north_star's scheme).  The total work is
+fixed as N grows ("strong" scaling).  Prints ONE JSON line on rank 0, which names the scheme that ran.
 
 PyTorch is plumbing here (device memory for the all-reduce buffer, streams, torch.distributed); all
 compute is the hand-written HIP library behind include/splat2d.h.
@@ -77,6 +82,39 @@ def cpu_baseline(W, H, n, threads):
     return out
 
 
+def kernel_source_digest():
+    """sha256[:16] over the kernel sources: ties a recorded profile (profiles/traffic.json) to the build it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "2dgaussiansplatting_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".inc")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n, argv):
+    """N > 1 without a launcher: start the ranks as a CHILD torch.distributed.run (this process has not touched the
+    GPU and never does), pass its output through, return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in proc.stdout:   # rank 0's JSON line goes to stdout; library chatter of the ranks to stderr
+        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
+        out.write(line)
+        out.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,7 +131,32 @@ def main():
                          "(distributed.HaloStep); 'dense' = replicated state, all-reduce of all N x 9 gradients")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                     "to rehearse the multi-process path with several ranks sharing one GPU)")
+    ap.add_argument("--launch-selftest", action="store_true",
+                    help="only check the multi-process launch path: the ranks rendezvous, all-reduce their rank numbers "
+                         "and rank 0 prints one JSON line; needs no GPU (tests/test_distributed_cpu.py)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    if args.launch_selftest:
+        import torch
+        import torch.distributed as dist_mod
+        world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist_mod.init_process_group(backend="gloo")
+        v = torch.tensor([rank + 1], dtype=torch.int64)
+        if world > 1:
+            dist_mod.all_reduce(v)
+            dist_mod.barrier()
+        if os.environ.get("S2D_BENCH_SELFTEST_FAIL_RANK") == str(rank):
+            sys.exit(7)  # lets the test see that a failing rank fails the whole command
+        if rank == 0:
+            print(json.dumps({"selftest": "launch", "world": world, "sum": int(v.item()), "gpus_arg": args.gpus}))
+        if world > 1:
+            dist_mod.destroy_process_group()
+        return
 
     import numpy as np
     import torch
@@ -104,9 +167,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world  # the launcher's world size wins
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: the trainer has no CPU fallback")
     device = local_rank % torch.cuda.device_count()  # == local_rank on a full node; ranks share a GPU only in gloo rehearsals
@@ -160,18 +221,26 @@ def main():
     for _ in range(args.warmup):
         one_step()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # step boundaries on the stream
+    rebuilds = []
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
+        marks[k].record(stream)
+        before = t.rebuild_count()
         one_step(events[k])
+        rebuilds.append(t.rebuild_count() != before)  # host-side counter, no synchronisation
+    marks[args.steps].record(stream)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     t.synchronize()  # raises if a parameter went non-finite
 
+    step_ms = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)], dtype=np.float64)
+    rebuilds = np.array(rebuilds, dtype=bool)
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     done = t.stats()["iterations"]
     first = done - args.steps
@@ -201,13 +270,30 @@ def main():
         bwd_bytes = 32.0 * W * (r1 - r0) + 72.0 * n
         bwd_s = float(bwd_ms.item()) * 1e-3
         achieved = bwd_bytes / bwd_s / 1e9 if bwd_s > 0 else 0.0
-        traffic = None
+        # HBM traffic of that kernel from the PMC counters: a RECORDED figure (rocprofv3 cannot run inside this
+        # process), valid only for the kernel build and the launch it was measured on -- dropped otherwise
+        traffic, traffic_note = None, "no PMC pass recorded for this build / launch"
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and world == 1 and (W, H, n) == (4096, 4096, 1000000):  # measured for this launch only
+        if os.path.exists(tp) and world == 1 and (W, H, n) == (4096, 4096, 1000000):
             try:
-                traffic = json.load(open(tp)).get("raster_backward_bytes_per_launch")
+                tj = json.load(open(tp))
+                if tj.get("kernel_source_digest") == kernel_source_digest():
+                    traffic = tj.get("raster_backward_bytes_per_launch")
+                    traffic_note = "recorded: %s" % tj.get("source")
+                else:
+                    traffic_note = "profiles/traffic.json was measured on another kernel build (digest %s): dropped" % tj.get("kernel_source_digest")
             except Exception:
-                traffic = None
+                pass
+        # "PSNR vs ref": the CPU oracle's trajectory on this very workload (tools/make_bench_reference_trace.py)
+        psnr_ref = None
+        rp = os.path.join(ROOT, "tests", "golden", "bench_reference_trace.json")
+        if os.path.exists(rp):
+            rj = json.load(open(rp))
+            it199 = done + extra - 1
+            if (rj["width"], rj["height"], rj["n_splats"]) == (W, H, n) and 0 <= it199 < len(rj["mse"]):
+                psnr_ref = 10.0 * float(np.log10(255.0 ** 2 / rj["mse"][it199]))
+        psnr_gpu = (10.0 * float(np.log10(255.0 ** 2 / (float(sq200[0].item()) / (H * W * 3)))) if sq200 is not None and float(sq200[0].item()) > 0 else None)
+        steady = step_ms[~rebuilds] if (~rebuilds).any() else step_ms
         out = {
             "metric": "train iters/sec (fwd+bwd+Adam) + PSNR vs ref; 4K img, 1M splats",
             "value": its,
@@ -216,6 +302,11 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / max(args.steps, 1),
+            # per-step durations from HIP events on the stream (rank 0): median, and the steps that rebuilt no tile list
+            "ms_per_step_median": float(np.median(step_ms)) if args.steps else None,
+            "iterations_per_s_median": (1e3 / float(np.median(step_ms))) if args.steps else None,
+            "iterations_per_s_steady_state": (1e3 / float(steady.mean())) if args.steps else None,
+            "steps_with_list_rebuild": int(rebuilds.sum()),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -229,7 +320,9 @@ def main():
             "mse_last": mse_last,
             "psnr_db_last": (10.0 * float(np.log10(255.0 ** 2 / mse_last)) if mse_last > 0 else None),
             "psnr_db_at_iteration": done + extra - 1,
-            "psnr_db": (10.0 * float(np.log10(255.0 ** 2 / (float(sq200[0].item()) / (H * W * 3)))) if sq200 is not None and float(sq200[0].item()) > 0 else None),
+            "psnr_db": psnr_gpu,
+            "psnr_ref_db": psnr_ref,  # the CPU oracle (reference loop) at the same iteration of the same workload
+            "psnr_delta_db": (psnr_gpu - psnr_ref) if (psnr_gpu is not None and psnr_ref is not None) else None,
             "iterations_total": stats["iterations"],
             "exchange_rank0": ({"scheme": "halo", "held_fraction": float(((step.mask >> rank) & 1).float().mean().item()),
                                 "rows_exchanged_per_iteration": int(sum(step.splits)), "state_handovers": int(step.handed_over)}
@@ -237,7 +330,7 @@ def main():
             "pairs_binned_rank0": stats["pairs_binned"],
             "rebins_rank0": stats["rebins"],
             "roofline": {"bound": "hbm", "kernel": "raster_backward_kernel", "achieved": achieved, "peak": 8000.0,
-                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel_ms": float(bwd_ms.item()), "algorithmic_bytes_per_launch": bwd_bytes},
         }
         if world == 1:

@@ -122,6 +122,8 @@ typedef struct s2d_stats {
     int32_t first_nonfinite_iteration; /* -1 if none */
     uint64_t fwd_staged_hit;   /* S2D_CFG_COUNT_PAIRS: staged entries that cover >= 1 pixel of their tile ... */
     uint64_t fwd_rows_hit;     /* ... and (staged entry, tile row) pairs with a non-empty column range (of 16 per entry) */
+    uint64_t phase_cycles[16]; /* zero except in -DS2D_PHASE_TIMING diagnostic builds (tools/build_timing_lib.py):
+                                * shader-clock cycles the raster kernels' waves spent per phase */
 } s2d_stats;
 
 typedef struct s2d_ctx s2d_ctx;
@@ -207,6 +209,8 @@ int s2d_get_sqerr_trace(s2d_ctx* ctx, int32_t first_iteration, int32_t count, do
 int s2d_synchronize(s2d_ctx* ctx);
 
 int s2d_get_stats(s2d_ctx* ctx, s2d_stats* out);
+/* s2d_stats.rebins without the device round trip s2d_get_stats makes (a host-side counter; never synchronises). */
+int s2d_get_rebuild_count(const s2d_ctx* ctx, uint64_t* rebuilds);
 const char* s2d_last_error(const s2d_ctx* ctx);
 
 /* ---- test hooks (used by tests/ through this ABI; not part of the training path) ---- */

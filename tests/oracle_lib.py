@@ -157,3 +157,106 @@ class OracleTrainer:
             st = self.L.s2do_step(*args)
         self.iterations += 1
         return st, mse.value
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Windowed sub-problems: the oracle on the part of a big scene that can reach one window of the image.
+#
+# A pixel's colour depends only on the splats whose loops visit it, blended in index order, and a splat's gradient
+# only on the pixels it visits.  So for a window [x0, x0+w) x [y0, y0+h):
+#   * `cand`   = every splat whose bounding circle (radius reach = 3*max(sx,sy)+2 around pos: it contains the
+#                reference's y-range, main.cpp:489-491, and every per-row x-range, :498-509, under any rotation)
+#                meets the window.  Run in their original order, they give every window pixel its exact colour.
+#   * `inside` = the candidates whose whole circle lies inside the window: ALL pixels they visit are window pixels,
+#                so the oracle's gradient for them on the sub-problem IS their gradient in the full scene.
+# ---------------------------------------------------------------------------------------------------------
+def window_subset(splats, win, W, H):
+    """-> (cand, inside): global indices (ascending) of the candidate splats, and of those fully inside (a window
+    edge that coincides with the image border clips footprints exactly as the reference's loops do)."""
+    x0, y0, w, h = win
+    px, py = splats["pos"][:, 0].astype(np.float64), splats["pos"][:, 1].astype(np.float64)
+    reach = 3.0 * np.maximum(splats["sx"], splats["sy"]).astype(np.float64) + 2.0
+    cand = (px + reach > x0) & (px - reach < x0 + w) & (py + reach > y0) & (py - reach < y0 + h)
+    inside = ((px - reach >= x0) | (x0 <= 0)) & ((px + reach <= x0 + w) | (x0 + w >= W)) & \
+             ((py - reach >= y0) | (y0 <= 0)) & ((py + reach <= y0 + h) | (y0 + h >= H)) & cand
+    return np.nonzero(cand)[0], np.nonzero(inside)[0]
+
+
+class WindowOracle:
+    """Oracle forward + backward (+ optional Adam step) on the candidates of one window of a W x H scene.
+    Rows outside [y0 - pad, y0 + h + pad) are never touched, so only that band of the images is allocated work;
+    the arrays themselves are full size (the oracle indexes pixels by their image coordinates)."""
+
+    def __init__(self, target, splats, win, adams=None, beta1t=1.0, beta2t=1.0):
+        self.win = win
+        self.cand, self.inside = window_subset(splats, win, target.shape[1], target.shape[0])
+        self.o = OracleTrainer(target, len(self.cand))
+        self.o.splats[:] = np.ascontiguousarray(splats[self.cand]).view(SPLAT_DTYPE)
+        if adams is not None:
+            self.o.adams[:] = np.ascontiguousarray(adams[self.cand]).view(ADAM_DTYPE)
+        self.o.beta1t[0], self.o.beta2t[0] = beta1t, beta2t
+        self.local_inside = np.searchsorted(self.cand, self.inside)   # rows of the inside splats in the sub-problem
+
+    def rows(self):
+        x0, y0, w, h = self.win
+        return max(0, y0), min(self.o.H, y0 + h)
+
+    def run(self):
+        """Forward + backward over the window's rows; returns (image0, w32, dsum, dabs) with the gradient arrays
+        restricted to the inside splats (their circles lie within the window's rows, so a row restriction loses
+        nothing for them)."""
+        o = self.o
+        r0, r1 = self.rows()
+        o.forward(r0, r1)
+        o.dsplats[:] = 0
+        dsum = np.zeros((o.n, 9), dtype=np.float64)
+        dabs = np.zeros((o.n, 9), dtype=np.float64)
+        o.L.s2do_backward_rows_stats(_p(o.splats), o.n, o.W, o.H, r0, r1, _p(o.image0), _p(o.ref), _p(o.image1),
+                                     _p(o.dsplats), _p(dsum), _p(dabs))
+        li = self.local_inside
+        w32 = o.dsplats.view(np.float32).reshape(-1, 9)[li].copy()
+        return o.image0, w32, dsum[li], dabs[li]
+
+    def adam_inside(self, lr=0.05):
+        """Adam + clamps on the sub-problem with the gradients `run` left; -> parameters of the inside splats."""
+        st = self.o.adam(lr)
+        return st, self.o.splats.view(np.float32).reshape(-1, 9)[self.local_inside].copy()
+
+
+def grad_bars(got, w32, dsum, dabs, rel=1e-4):
+    """The three gradient bars (tests/test_gpu_parity.py docstring) for (m, 9) arrays: the HIP path's sums `got`, the
+    oracle's fp32 sums `w32` (the reference's sequential order), the same terms summed in double `dsum`, and the sum of
+    their magnitudes `dabs`.  Asserts them and returns the measured maxima."""
+    g = np.asarray(got, dtype=np.float64).reshape(-1, 9)
+    w = np.asarray(w32, dtype=np.float64).reshape(-1, 9)
+    dsum = np.asarray(dsum, dtype=np.float64).reshape(-1, 9)
+    dabs = np.asarray(dabs, dtype=np.float64).reshape(-1, 9)
+    nz = dabs > 0
+    assert np.all(g[~nz] == 0)                      # splats that touch no live pixel get exactly zero
+    e_gpu = np.abs(g - dsum)[nz] / dabs[nz]
+    e_ref = np.abs(w - dsum)[nz] / dabs[nz]
+    a, b_ref = float(e_gpu.max()), float(e_ref.max())
+    c = float((np.abs(g - w)[nz] / np.maximum(np.abs(w[nz]), 0.02 * dabs[nz])).max())
+    assert a <= 1e-6, a                             # (a) the exact sum to fp32 summation accuracy
+    assert a <= b_ref, (a, b_ref)                   # (b) at least as close to it as the reference's own fp32 sum
+    assert c <= rel, c                              # (c) 1e-4 against the oracle wherever the sum keeps >= 2 % of its terms
+    return {"a_gpu_vs_exact": a, "b_ref_vs_exact": b_ref, "c_gpu_vs_oracle": c}
+
+
+def ulp32(x):
+    """Spacing of binary32 at |x| (elementwise)."""
+    x = np.abs(np.asarray(x, dtype=np.float32))
+    return (np.nextafter(x, np.float32(np.inf)) - x).astype(np.float64)
+
+
+def step_delta_error(before, got_after, want_after, lr=0.05):
+    """One optimiser step from identical state, judged on the UPDATE: |delta_gpu - delta_oracle| / lr per scalar, after
+    forgiving one unit in the last place of the parameter (both sides round the same double-precision update to
+    binary32 once, main.cpp:155; where the two updates straddle a rounding boundary the results differ by one ulp,
+    which at pos ~ 4000 is 2.4e-4, i.e. 0.5 % of a 0.05 step -- not an arithmetic difference)."""
+    b = np.asarray(before, dtype=np.float64)
+    g = np.asarray(got_after, dtype=np.float64)
+    w = np.asarray(want_after, dtype=np.float64)
+    d = np.abs((g - b) - (w - b))
+    d = np.maximum(d - ulp32(want_after), 0.0)
+    return d / lr

@@ -255,3 +255,26 @@ def test_gloo_slab_ownership_without_margin_fails_on_every_rank(tmp_path):
     with pytest.raises(Exception) as ei:
         mp.spawn(_halo_worker, args=(2, _free_port(), 12, 600, 3, 0.0, out), nprocs=2, join=True)
     assert "handed over" in str(ei.value)
+
+
+def test_bench_spawns_its_ranks_from_the_plain_command():
+    """`python bench.py --gpus 2` with no launcher environment must start its two ranks itself (as a child
+    torch.distributed.run), relay rank 0's JSON line and return non-zero when a rank fails.  --launch-selftest stops
+    each rank after the rendezvous + an all-reduce, so this runs without a GPU; the GPU suite runs the real thing
+    (tests/test_gpu_fullsize.py::test_bench_plain_command_two_ranks_gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line on stdout
+    out = json.loads(lines[0])
+    assert out == {"selftest": "launch", "world": 2, "sum": 3, "gpus_arg": 2}
+    env["S2D_BENCH_SELFTEST_FAIL_RANK"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0

@@ -97,6 +97,32 @@ KERNEL(k_swap16_x8, "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3
                     "v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7\n"
                     "v_permlane16_swap_b32 %0, %2\n v_permlane16_swap_b32 %1, %3\n v_permlane16_swap_b32 %4, %6\n v_permlane16_swap_b32 %5, %7\n")
 
+// Does the SIMD skip the half (or quarter) of a wave64 whose EXEC bits are all zero?  The same v_fma stream with
+// only some lanes enabled (the loop's trip count is uniform, so EXEC can simply be narrowed around it).
+#define KERNEL_EXEC(name, lo, hi)                                                                                    \
+    __global__ void name(float* out, unsigned long long* clk, int iters)                                             \
+    {                                                                                                                \
+        float a0 = threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7; \
+        float b0 = 1.0001f, b1 = 0.9999f;                                                                            \
+        const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();                             \
+        asm volatile("s_mov_b32 exec_lo, " lo "\n s_mov_b32 exec_hi, " hi "\n" ::: "memory");                        \
+        for (int i = 0; i < iters; i++) {                                                                            \
+            asm volatile(X8(OP_FMA)                                                                                  \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)            \
+                         : "v"(b0), "v"(b1));                                                                        \
+        }                                                                                                            \
+        asm volatile("s_mov_b64 exec, -1\n" ::: "memory");                                                           \
+        const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();                             \
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = c1 - c0; clk[1] = w1 - w0; }                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                          \
+    }
+KERNEL_EXEC(k_fma_exec_lo32, "0xffffffff", "0")
+KERNEL_EXEC(k_fma_exec_hi32, "0", "0xffffffff")
+KERNEL_EXEC(k_fma_exec_lo16, "0xffff", "0")
+KERNEL_EXEC(k_fma_exec_even, "0x55555555", "0x55555555")
+KERNEL_EXEC(k_fma_exec_rows02, "0x0000ffff", "0x0000ffff")
+KERNEL_EXEC(k_fma_exec_one, "1", "0")
+
 // packed fp32: 8 independent register pairs
 typedef float pk2 __attribute__((ext_vector_type(2)));
 #define PK_MUL(n) "v_pk_mul_f32 %" #n ", %" #n ", %8\n"
@@ -173,6 +199,9 @@ int main(int argc, char** argv)
         {"v_cmp_lt_f32 -> vcc", k_cmpvcc_x8}, {"v_cmp_lt_f32 -> sgpr pair", k_cmpsgpr_x8}, {"v_cndmask_b32 vcc", k_cndvcc_x8},
         {"v_cndmask_b32 sgpr pair", k_cndsgpr_x8}, {"v_readlane_b32", k_readlane_x8}, {"v_readfirstlane_b32", k_readfirst_x8},
         {"v_permlane32_swap", k_swap32_x8}, {"v_permlane16_swap", k_swap16_x8},
+        {"v_fma_f32 x8, EXEC = lanes 0-31", k_fma_exec_lo32}, {"v_fma_f32 x8, EXEC = lanes 32-63", k_fma_exec_hi32},
+        {"v_fma_f32 x8, EXEC = lanes 0-15", k_fma_exec_lo16}, {"v_fma_f32 x8, EXEC = even lanes", k_fma_exec_even},
+        {"v_fma_f32 x8, EXEC = rows 0 and 2", k_fma_exec_rows02}, {"v_fma_f32 x8, EXEC = lane 0", k_fma_exec_one},
         {"v_pk_mul_f32 x8", k_pkmul_x8}, {"v_pk_add_f32 x8", k_pkadd_x8}, {"v_pk_fma_f32 x8", k_pkfma_x8}, {"v_pk_mov_b32 x8", k_pkmov_x8},
     };
     const std::vector<K> mixed = {{"(v_mul_f32 + s_and_b32) pairs", k_mul_s_x8}, {"(v_mul_f32 + s_nop) pairs", k_mul_nop_x8}};
