@@ -200,7 +200,7 @@ int launch_forward(s2d_ctx* c, bool optimistic)
     const int abort_stamp = optimistic ? c->check_seq : 0;
     S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->half_images, c->d_wave_masks,
                                      c->g, c->d_status, abort_stamp, c->iterations, c->d_counters, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) != 0,
-                                     c->stream));
+                                     (c->cfg.flags & S2D_CFG_EXACT_EXP) != 0, c->stream));
     return S2D_OK;
 }
 
@@ -255,7 +255,8 @@ int queue_backward(s2d_ctx* c, bool need_opacity_grad)
     S2D_HIP(c, launch_raster_backward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->half_images,
                                       c->d_wave_masks, c->d_grads,
                                       c->d_tile_sqerr, c->g, need_opacity_grad, c->deterministic ? &dg : nullptr,
-                                      c->d_status, c->iterations, c->d_counters, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) != 0, c->stream));
+                                      c->d_status, c->iterations, c->d_counters, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) != 0,
+                                      (c->cfg.flags & S2D_CFG_EXACT_EXP) != 0, c->stream));
     S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->d_tile_sqerr + c->g.num_tiles,
                                      c->d_status, c->iterations, c->stream));
     c->last_sqerr_slot = slot;
@@ -273,7 +274,8 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
     if (fuse) c->check_seq++;
     S2D_HIP(c, launch_adam(c->d_splats, c->d_adams, c->d_grads, c->d_held_ids, c->d_held_count, c->n, c->g, c->beta1t, c->beta2t,
                            c->lr,
-                           (flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0, c->iterations, c->d_status,
+                           ((flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0) | ((c->cfg.flags & S2D_CFG_ADAM_FP32) ? 2 : 0),
+                           c->iterations, c->d_status,
                            fuse ? c->d_proj : nullptr, c->d_rects, c->check_seq, c->h_rebin_stamp, c->stream));
     if (fuse) S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
     c->proj_fresh = fuse;
@@ -333,6 +335,7 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     int rb = cfg->row_begin, re = cfg->row_end;
     if (rb == 0 && re == 0) re = cfg->height;
     if (rb < 0 || re > cfg->height || rb >= re || (rb % kTile) != 0) return S2D_E_INVALID;
+    if ((cfg->flags & S2D_CFG_EXACT_EXP) && (cfg->flags & (S2D_CFG_COUNT_PAIRS | S2D_CFG_FP16_IMAGES))) return S2D_E_INVALID;
 
     s2d_ctx* c = new (std::nothrow) s2d_ctx();
     if (!c) return S2D_E_NOMEM;

@@ -156,7 +156,8 @@ hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, 
 // parameter went non-finite in an earlier iteration (status->first_nonfinite_iter < iteration).
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
                                  bool half_images, unsigned long long* wave_masks, Geometry g, const DeviceStatus* status,
-                                 int abort_stamp, int iteration, PairCounters* counters, bool count, hipStream_t stream);
+                                 int abort_stamp, int iteration, PairCounters* counters, bool count, bool exact_exp,
+                                 hipStream_t stream);
 // Deterministic gradient accumulation (S2D_CFG_DETERMINISTIC): instead of float atomics every tile stores its
 // partial gradient of a splat into the slot offsets[splat] + (position of the tile in the splat's emission
 // rectangle), stamped with the iteration; a gather kernel then sums each splat's stamped slots in slot order.
@@ -173,7 +174,7 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
                                   const void* image0, const void* image_ref, bool half_images,
                                   const unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
                                   bool need_opacity_grad, const DetGather* dg, const DeviceStatus* status, int iteration,
-                                  PairCounters* counters, bool count, hipStream_t stream);
+                                  PairCounters* counters, bool count, bool exact_exp, hipStream_t stream);
 // Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
 // slab ownership (s2d_halo.hip): `held` == nullptr means every splat is held (single rank, or replicated state)
 hipError_t launch_halo_masks(const float* splats, const uint8_t* held, int n, int world, const int* row_bounds, float margin,

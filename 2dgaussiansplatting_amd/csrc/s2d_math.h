@@ -306,11 +306,15 @@ S2D_HD Splat init_splat(uint32_t i, int W, int H)
 }
 
 // ----------------------------------------------------------------------------------------------
-// Adam::optimize, main.cpp:144-156.  `sqrt` at :155 is unqualified and binds ::sqrt(double) in the
-// Linux build the known-answer vectors come from: the quotient and the subtraction are evaluated
-// in double and rounded to float once.  m, v, m_hat, v_hat, s*m_hat are fp32.
+// Adam::optimize, main.cpp:144-156.  `sqrt` at :155 is unqualified.  In the Linux build the known-answer vectors
+// come from (g++ / clang++) it binds ::sqrt(double): the quotient and the subtraction are
+// evaluated in double and rounded to float once -- the default here, because that is what the oracle can be pinned
+// to.  The reference itself is an MSVC program, where <cmath> puts the float overload of sqrt in the global
+// namespace and the whole expression is fp32: `fp32_quotient` (S2D_CFG_ADAM_FP32) selects that form.  The two differ
+// by at most one ulp of the parameter plus ~3 ulp of the 0.05 update per step (tests/test_oracle_kat.py).  m, v, m_hat, v_hat, s*m_hat are fp32 either way.
 // ----------------------------------------------------------------------------------------------
-S2D_HD float adam_optimize(float& m_m, float& m_v, float value, float g, float alpha, float beta1t, float beta2t)
+S2D_HD float adam_optimize(float& m_m, float& m_v, float value, float g, float alpha, float beta1t, float beta2t,
+                           bool fp32_quotient = false)
 {
     float m = kAdamBeta1 * m_m + (1.0f - kAdamBeta1) * g;
     float v = kAdamBeta2 * m_v + (1.0f - kAdamBeta2) * g * g;
@@ -320,6 +324,8 @@ S2D_HD float adam_optimize(float& m_m, float& m_v, float value, float g, float a
     float v_hat = v / (1.0f - beta2t);
     const float ADAM_E = 1.0e-15f;
     float sm = alpha * m_hat;
+    if (fp32_quotient)
+        return value - sm / (sqrt_f32(v_hat) + ADAM_E); // MSVC: sqrt(float) -> float
     return (float)((double)value - (double)sm / (::sqrt((double)v_hat) + (double)ADAM_E));
 }
 

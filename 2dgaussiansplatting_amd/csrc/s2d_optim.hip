@@ -56,9 +56,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
 #pragma unroll
     for (int k = 0; k < 9; k++) {
         v[k] = sp[k];
-        if (k < 8 || optimize_opacity) { // main.cpp:735-738
+        if (k < 8 || (optimize_opacity & 1)) { // main.cpp:735-738; bit 1 of the argument: fp32 Adam quotient
             float m_m = ad[2 * k], m_v = ad[2 * k + 1];
-            v[k] = adam_optimize(m_m, m_v, v[k], gr[k], lr, beta1t, beta2t);
+            v[k] = adam_optimize(m_m, m_v, v[k], gr[k], lr, beta1t, beta2t, (optimize_opacity & 2) != 0);
             ad[2 * k] = m_m;
             ad[2 * k + 1] = m_v;
         }

@@ -145,7 +145,20 @@ __device__ __forceinline__ int stage_masks(uint32_t* s_mask32, int se, int sub, 
 // ---------------------------------------------------------------------------------------------------
 // forward, main.cpp:414-546
 // ---------------------------------------------------------------------------------------------------
-template <bool COUNT, bool HALF>
+// EXACT (S2D_CFG_EXACT_EXP): G = expf(-d2/2) instead of exp_approx -- the switch the reference keeps at main.cpp:51
+// "for numerical varidation": the analytic gradients are those of the TRUE exponential, so only in this mode is the
+// backward pass the derivative of the forward pass (tests/test_gpu_fd.py checks exactly that by finite differences).
+template <bool EXACT>
+__device__ __forceinline__ float gauss_of(float d2, bool* nonzero)
+{
+    if (EXACT) {
+        *nonzero = true;
+        return expf(-0.5f * d2); // main.cpp:51, :527
+    }
+    return gauss_pow8(d2, nonzero);
+}
+
+template <bool COUNT, bool HALF, bool EXACT>
 __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __restrict__ tile_off,
                                                              const uint32_t* __restrict__ list,
                                                              const ProjRec* __restrict__ proj,
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                 const f2 m = mk2(q0.z, q0.w) * v.x + mk2(q1.x, q1.y) * v.y;  // inv_cov * v: (a vx + b vy, b vx + d vy)
                 const f2 vm = v * m;
                 bool nonzero;
-                const float G = gauss_pow8(vm.x + vm.y, &nonzero);           // main.cpp:526-527
+                const float G = gauss_of<EXACT>(vm.x + vm.y, &nonzero);      // main.cpp:526-527
                 const unsigned long long on = act & __ballot(nonzero);
                 const float alpha = __builtin_amdgcn_inverse_ballot_w64(on) ? G * q2.y : 0.0f;
                 crg += (T * mk2(q1.z, q1.w)) * alpha;                        // main.cpp:529-530: (T*c)*alpha
@@ -383,7 +396,7 @@ struct DetSlots {
     uint32_t now;             // iteration + 1
 };
 
-template <bool COUNT, bool NEED_OP, bool HALF, bool DET>
+template <bool COUNT, bool NEED_OP, bool HALF, bool DET, bool EXACT>
 __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
                                                               const uint32_t* __restrict__ list,
                                                               const ProjRec* __restrict__ proj,
@@ -520,7 +533,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                     const f2 m = mk2(q0.z, q0.w) * v.x + mk2(q1.x, q1.y) * v.y;      // inv_cov * v
                     const f2 vm = v * m;
                     bool nonzero;
-                    const float G = gauss_pow8(vm.x + vm.y, &nonzero);               // main.cpp:609-610
+                    const float G = gauss_of<EXACT>(vm.x + vm.y, &nonzero);          // main.cpp:609-610
                     // one scalar mask selects alpha (and dOpacity): visited, alive, and G not cut to 0
                     const bool on = __builtin_amdgcn_inverse_ballot_w64(act_mask & __ballot(nonzero));
                     const float alpha = on ? G * q2.y : 0.0f;                        // main.cpp:611
@@ -714,13 +727,17 @@ static inline unsigned raster_grid(int num_tiles) { return (unsigned)(((num_tile
 
 hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
                                  bool half_images, unsigned long long* wave_masks, Geometry g, const DeviceStatus* status,
-                                 int abort_stamp, int iteration, PairCounters* counters, bool count, hipStream_t stream)
+                                 int abort_stamp, int iteration, PairCounters* counters, bool count, bool exact_exp,
+                                 hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
 #define S2D_LAUNCH_FWD(C, H) \
-    hipLaunchKernelGGL((raster_forward_kernel<C, H>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, status, abort_stamp, iteration, counters)
-    if (count) {
+    hipLaunchKernelGGL((raster_forward_kernel<C, H, false>), grid, block, 0, stream, tile_off, list, proj, image0, wave_masks, g, status, abort_stamp, iteration, counters)
+    if (exact_exp) { // validation mode: plain fp32 images, no pair counting (s2d_create rejects the combinations)
+        hipLaunchKernelGGL((raster_forward_kernel<false, false, true>), grid, block, 0, stream, tile_off, list, proj, image0,
+                           wave_masks, g, status, abort_stamp, iteration, counters);
+    } else if (count) {
         if (half_images) S2D_LAUNCH_FWD(true, true); else S2D_LAUNCH_FWD(true, false);
     } else {
         if (half_images) S2D_LAUNCH_FWD(false, true); else S2D_LAUNCH_FWD(false, false);
@@ -733,18 +750,25 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
                                   const void* image0, const void* image_ref, bool half_images,
                                   const unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
                                   bool need_opacity_grad, const DetGather* dg, const DeviceStatus* status, int iteration,
-                                  PairCounters* counters, bool count, hipStream_t stream)
+                                  PairCounters* counters, bool count, bool exact_exp, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
     DetSlots det{nullptr, nullptr, nullptr, nullptr, 0u};
     if (dg) det = DetSlots{dg->rects, dg->offsets, dg->data, dg->stamp, dg->now};
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
 #define S2D_LAUNCH_BWD(C, O, H, D)                                                                                       \
-    hipLaunchKernelGGL((raster_backward_kernel<C, O, H, D>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
+    hipLaunchKernelGGL((raster_backward_kernel<C, O, H, D, false>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
                        wave_masks, grads, tile_sqerr, g, det, status, iteration, counters)
 #define S2D_LAUNCH_BWD_D(C, O, H) do { if (dg) S2D_LAUNCH_BWD(C, O, H, true); else S2D_LAUNCH_BWD(C, O, H, false); } while (0)
 #define S2D_LAUNCH_BWD_H(C, O) do { if (half_images) S2D_LAUNCH_BWD_D(C, O, true); else S2D_LAUNCH_BWD_D(C, O, false); } while (0)
-    if (count) {
+    if (exact_exp) {
+#define S2D_LAUNCH_BWD_X(O, D)                                                                                           \
+    hipLaunchKernelGGL((raster_backward_kernel<false, O, false, D, true>), grid, block, 0, stream, tile_off, list, proj, image0, \
+                       image_ref, wave_masks, grads, tile_sqerr, g, det, status, iteration, counters)
+        if (need_opacity_grad) { if (dg) S2D_LAUNCH_BWD_X(true, true); else S2D_LAUNCH_BWD_X(true, false); }
+        else { if (dg) S2D_LAUNCH_BWD_X(false, true); else S2D_LAUNCH_BWD_X(false, false); }
+#undef S2D_LAUNCH_BWD_X
+    } else if (count) {
         if (need_opacity_grad) S2D_LAUNCH_BWD_H(true, true); else S2D_LAUNCH_BWD_H(true, false);
     } else {
         if (need_opacity_grad) S2D_LAUNCH_BWD_H(false, true); else S2D_LAUNCH_BWD_H(false, false);

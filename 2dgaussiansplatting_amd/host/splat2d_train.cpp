@@ -168,10 +168,13 @@ int main(int argc, char** argv)
         o.iters += iterations; // --iters counts iterations to run from the checkpoint
     }
     std::vector<double> mse((size_t)o.batch);
+    int frames = 0; // iterations run by this process (the trace numbering restarts at Restart, this does not)
     const auto t0 = std::chrono::steady_clock::now();
     while (iterations < o.iters) { // while (pr::NextFrame() == false), main.cpp:334
-        if (iterations == o.restart_at) { // ImGui::Button("Restart"), main.cpp:828-831
-            CK(s2d_init_splats(ctx));
+        if (iterations == o.restart_at) { // ImGui::Button("Restart"), main.cpp:828-831: init() also sets
+            CK(s2d_init_splats(ctx));     // iterations = 0 (main.cpp:281), so the trace restarts at "0 itr"
+            o.iters -= iterations;        // --iters is the number of frames to run in total
+            iterations = 0;
             o.restart_at = -1;
         }
         int k = o.batch;
@@ -183,10 +186,12 @@ int main(int argc, char** argv)
         if (!o.quiet)
             for (int j = 0; j < k; j++) std::printf("%d itr, mse %.4f\n", iterations + j, mse[(size_t)j]); // main.cpp:807
         iterations += k; // main.cpp:809
+        frames += k;
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats)\n", iterations, secs,
-                 secs > 0 ? iterations / secs : 0.0, W, H, o.n_splats);
+    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats)\n", frames, secs,
+                 secs > 0 ? frames / secs : 0.0, W, H, o.n_splats);
+    int exit_code = 0; // an output file that cannot be written is an error, reported after everything else was tried
 
     if (!o.save_ckpt.empty()) {
         CkptHeader h;
@@ -201,22 +206,31 @@ int main(int argc, char** argv)
                         std::fwrite(sp.data(), sizeof(s2d_splat), sp.size(), f) == sp.size() &&
                         std::fwrite(ad.data(), sizeof(s2d_splat_adam), ad.size(), f) == ad.size();
         if (f) std::fclose(f);
-        if (!ok) std::fprintf(stderr, "cannot write %s\n", o.save_ckpt.c_str());
+        if (!ok) {
+            std::fprintf(stderr, "cannot write %s\n", o.save_ckpt.c_str());
+            exit_code = 1;
+        }
     }
     if (!o.out_image.empty() || !o.overlay.empty()) {
         std::vector<float> image0((size_t)W * H * 4);
         CK(s2d_forward(ctx));
         CK(s2d_get_image(ctx, image0.data())); // tex0->upload(image0), main.cpp:794
         const s2dio::Image8 im = s2dio::quantise(image0, W, H);
-        if (!o.out_image.empty() && !s2dio::save_image(o.out_image, im)) std::fprintf(stderr, "cannot write %s\n", o.out_image.c_str());
+        if (!o.out_image.empty() && !s2dio::save_image(o.out_image, im)) {
+            std::fprintf(stderr, "cannot write %s\n", o.out_image.c_str());
+            exit_code = 1;
+        }
         if (!o.overlay.empty()) { // the reference's splat visualisation, main.cpp:441-485
             std::vector<s2d_splat> sp((size_t)o.n_splats);
             CK(s2d_get_splats(ctx, sp.data()));
             s2dio::Image8 big = s2dio::upscale(im, o.overlay_scale);
             s2dio::draw_splat_overlay(&big, sp, o.overlay_scale, o.overlay_stride);
-            if (!s2dio::save_image(o.overlay, big)) std::fprintf(stderr, "cannot write %s\n", o.overlay.c_str());
+            if (!s2dio::save_image(o.overlay, big)) {
+                std::fprintf(stderr, "cannot write %s\n", o.overlay.c_str());
+                exit_code = 1;
+            }
         }
     }
     s2d_destroy(ctx);
-    return 0;
+    return exit_code;
 }

@@ -89,6 +89,18 @@ typedef enum s2d_status {
                                   * Not the reference's arithmetic: results equal the reference run with imageRef and
                                   * image0 rounded to fp16 (tests/test_gpu_parity.py::test_fp16_images_*). */
 
+#define S2D_CFG_EXACT_EXP 0x8u   /* validation mode: exp_approx returns expf(x), the switch the reference keeps at
+                                  * main.cpp:51 "for numerical varidation".  The analytic gradients (main.cpp:639-704) are
+                                  * those of the true exponential, so in this mode the backward pass is the derivative of
+                                  * the forward pass and a finite-difference check closes (tests/test_gpu_fd.py).  Not
+                                  * combinable with S2D_CFG_COUNT_PAIRS / S2D_CFG_FP16_IMAGES. */
+
+#define S2D_CFG_ADAM_FP32 0x10u  /* Adam::optimize (main.cpp:155) with the quotient and subtraction in fp32, as the
+                                  * reference's own MSVC build evaluates the unqualified `sqrt` (float overload).  Default:
+                                  * the double-precision quotient of a g++/clang++ build, which is what the known-answer
+                                  * vectors pin.  The two differ by <= 1 ulp of the parameter
+                                  * + ~3 ulp of the update per step; 100-iteration traces by a few 1e-4 (test_oracle_kat.py). */
+
 typedef struct s2d_config {
     uint32_t struct_size;   /* = sizeof(s2d_config) */
     int32_t width, height;  /* imageRef.width(), .height() (main.cpp:254) */

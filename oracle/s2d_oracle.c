@@ -44,9 +44,17 @@ static inline float sign_of(float v) { return v < 0.0f ? -1.0f : 1.0f; }
 static inline float ss_max(float x, float y) { return (x < y) ? y : x; }
 static inline float ss_min(float x, float y) { return (y < x) ? y : x; }
 
+/* main.cpp:51: "return expf( x ); // use this for numerical varidation" -- a process-wide switch of this test
+ * library (never set while the known-answer tests run): when on, exp_approx IS expf, as in the reference with that
+ * line un-commented. */
+static int g_exact_exp = 0;
+void s2do_set_exact_exp(int on) { g_exact_exp = on; }
+
 /* main.cpp:49-83 */
 float s2do_exp_approx(float x)
 {
+    if (g_exact_exp)
+        return expf(x); /* main.cpp:51 */
     x = 1.0f + x / 8.0f;
     if (x < 0.00001814586175896693021059036255f) /* avoid subnormal */
         return 0.0f;
@@ -331,6 +339,12 @@ void s2do_backward_rows_stats(const s2do_splat* splats, int n, int W, int H, int
  * the survey's known-answer vectors were captured) it binds ::sqrt(double), so the
  * quotient and the final subtraction are evaluated in double and rounded to float on
  * return; `s * m_hat` is still a float product. */
+/* The reference is an MSVC program; there the unqualified sqrt binds the float overload and the expression is fp32
+ * throughout.  s2do_set_adam_fp32(1) selects that form (process-wide switch of this test library, off while the
+ * known-answer tests run): it lets the tests measure what the unverifiable choice costs. */
+static int g_adam_fp32 = 0;
+void s2do_set_adam_fp32(int on) { g_adam_fp32 = on; }
+
 static inline float adam_optimize(s2do_adam* st, float value, float g, float alpha, float beta1t, float beta2t)
 {
     float s = alpha;
@@ -342,6 +356,8 @@ static inline float adam_optimize(s2do_adam* st, float value, float g, float alp
     float v_hat = v / (1.0f - beta2t);
     const float ADAM_E = 1.0e-15f;
     float sm = s * m_hat;
+    if (g_adam_fp32)
+        return value - sm / (sqrtf(v_hat) + ADAM_E);
     return (float)((double)value - (double)sm / (sqrt((double)v_hat) + (double)ADAM_E));
 }
 

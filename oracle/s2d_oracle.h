@@ -110,6 +110,11 @@ float s2do_sinf(float x);
 
 /* main.cpp:49-83 */
 float s2do_exp_approx(float x);
+/* main.cpp:155 as an MSVC build evaluates it (sqrt(float) -> float, all-fp32 update) instead of the g++ form
+ * (double quotient) the known-answer vectors were captured with. */
+void s2do_set_adam_fp32(int on);
+/* main.cpp:51: switch exp_approx to expf for every later call ("use this for numerical varidation"). */
+void s2do_set_exact_exp(int on);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,8 @@ def lib():
     L.s2do_sinf.argtypes = [f]; L.s2do_sinf.restype = f
     L.s2do_exp_approx.argtypes = [f]; L.s2do_exp_approx.restype = f
     L.s2do_pcg3d.argtypes = [vp]
+    L.s2do_set_exact_exp.argtypes = [i]
+    L.s2do_set_adam_fp32.argtypes = [i]
     _lib = L
     return L
 

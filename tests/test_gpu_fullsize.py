@@ -232,9 +232,10 @@ def test_native_535x426_50k_gradients_and_step(steps):
 
 def test_bench_workload_follows_the_reference_trajectory():
     """"PSNR vs ref" (BASELINE metric): the oracle's MSE trace on bench.py's workload is committed
-    (tests/golden/bench_reference_trace.json, tools/make_bench_reference_trace.py).  The first iterations must agree to
-    2e-5 (only the fp32 order of the gradient sums differs), the PSNR at iteration 199 to 0.1 dB (the trajectory is
-    chaotic, SURVEY.md section 7 hard part 2, so only a band is meaningful that far out)."""
+    (tests/golden/bench_reference_trace.json, tools/make_bench_reference_trace.py).  Only the fp32 order of the
+    gradient sums differs between the two: the first iterations must agree to 1e-6 relative, every PSNR of the 200
+    iterations to 0.02 dB and the one at iteration 199 to 0.01 dB (measured: 1.2e-8, 0.0013 dB, 0.0001 dB; the
+    trajectory is chaotic in the long run, SURVEY.md section 7 hard part 2, hence bands rather than digits)."""
     rj = json.load(open(os.path.join(O.GOLDEN, "bench_reference_trace.json")))
     ref = np.array(rj["mse"])
     with S2D.Trainer(rj["width"], rj["height"], rj["n_splats"]) as t:
@@ -247,8 +248,8 @@ def test_bench_workload_follows_the_reference_trajectory():
     d = np.abs(psnr - psnr_ref)
     _report("bench workload vs oracle trace", {"rel_mse_it0_10": rel.max(), "psnr_gpu_199": psnr[199], "psnr_ref_199": psnr_ref[199],
                                                "max_abs_dpsnr_0_199": d.max(), "dpsnr_199": d[199]})
-    assert rel[0] <= 1e-9 and rel.max() <= 2e-5
-    assert d[199] <= 0.1 and d[:100].max() <= 0.1 and d.max() <= 0.25
+    assert rel[0] <= 1e-9 and rel.max() <= 1e-6
+    assert d[199] <= 0.01 and d.max() <= 0.02
 
 
 def test_bench_plain_command_two_ranks_gloo():

@@ -664,7 +664,12 @@ def test_cpp_host_checkpoint_and_ppm(tmp_path):
     # restart button: the trace starts over from the init() state
     r = subprocess.run([exe, "--image", MINI, "--splats", "1024", "--iters", "5", "--restart-at", "3"], capture_output=True,
                        text=True, check=True).stdout.strip().splitlines()
-    assert r[3].endswith("mse 5934.9042") and r[0].endswith("mse 5934.9042")
+    assert r[3] == "0 itr, mse 5934.9042" and r[0] == "0 itr, mse 5934.9042"   # init() resets iterations (main.cpp:281)
+    assert [int(l.split()[0]) for l in r] == [0, 1, 2, 0, 1] and r[4] == r[1]
+    # an output file that cannot be written is an error
+    bad = subprocess.run([exe, "--image", MINI, "--splats", "64", "--iters", "1", "--out-image", "/nonexistent-dir/x.ppm"],
+                         capture_output=True, text=True)
+    assert bad.returncode == 1 and "cannot write" in bad.stderr
 
 
 def test_against_committed_oracle_golden():
@@ -975,3 +980,25 @@ def test_row_level_abi_calls_against_numpy():
         after = t.get_splats().view(np.float32).reshape(n, 9)
         assert after[1::2].tobytes() == before[1::2].tobytes()
         assert (after[0::2] != before[0::2]).any()
+
+
+def test_adam_fp32_quotient_mode_matches_the_oracle_in_that_mode():
+    """S2D_CFG_ADAM_FP32 (the reference's MSVC evaluation of main.cpp:155): one step from identical state against the
+    oracle with the same switch, to the same bar as the default double-precision form."""
+    tgt = mini_target()
+    try:
+        O.lib().s2do_set_adam_fp32(1)
+        o, t0 = make_pair(tgt, 2000, 4)
+        t0.close()
+        before = o.splats.view(np.float32).reshape(-1, 9).copy()
+        with S2D.Trainer(o.W, o.H, 2000, adam_fp32=True) as t:
+            t.set_target(tgt)
+            t.set_splats(o.splats.view(S2D.SPLAT_DTYPE))
+            t.set_adam(o.adams.view(S2D.ADAM_DTYPE), o.beta1t[0], o.beta2t[0], o.iterations)
+            o.step()
+            t.step(1)
+            got = t.get_splats().view(np.float32).reshape(-1, 9)
+    finally:
+        O.lib().s2do_set_adam_fp32(0)
+    err = O.step_delta_error(before, got, o.splats.view(np.float32).reshape(-1, 9))
+    assert err.max() <= STEP_REL, err.max()
