@@ -56,14 +56,14 @@ class _Stats(C.Structure):
                 ("bwd_active", C.c_uint64), ("fwd_staged", C.c_uint64), ("bwd_staged", C.c_uint64),
                 ("fwd_wave_execs", C.c_uint64), ("bwd_wave_execs", C.c_uint64), ("bwd_lane_hist", C.c_uint64 * 65),
                 ("iterations", C.c_int32), ("first_nonfinite_iteration", C.c_int32),
-                ("fwd_staged_hit", C.c_uint64), ("fwd_rows_hit", C.c_uint64), ("phase_cycles", C.c_uint64 * 16)]
+                ("fwd_staged_hit", C.c_uint64), ("fwd_rows_hit", C.c_uint64)]
 
 
 # every symbol include/splat2d.h declares
 ABI_SYMBOLS = [
     "s2d_abi_version", "s2d_create", "s2d_destroy", "s2d_set_target", "s2d_set_target_synthetic",
     "s2d_init_splats", "s2d_set_splats", "s2d_get_splats", "s2d_set_adam", "s2d_get_adam", "s2d_forward",
-    "s2d_get_image", "s2d_backward", "s2d_get_grads", "s2d_adam_step", "s2d_step", "s2d_get_mse",
+    "s2d_get_image", "s2d_backward", "s2d_forward_backward", "s2d_get_grads", "s2d_adam_step", "s2d_step", "s2d_get_mse",
     "s2d_bind_grads_device", "s2d_grads_device_ptr", "s2d_get_sqerr_trace", "s2d_synchronize", "s2d_get_stats",
     "s2d_get_rebuild_count",
     "s2d_last_error", "s2d_test_sincos", "s2d_test_sort_pairs", "s2d_test_exclusive_scan",
@@ -85,42 +85,53 @@ def load_library(path=None):
                            "(the trainer has no CPU fallback)" % path)
     L = C.CDLL(path)
     vp, i32, u32, i64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64
-    L.s2d_abi_version.restype = C.c_int
-    L.s2d_create.argtypes = [C.POINTER(_Config), C.POINTER(vp)]
-    L.s2d_destroy.argtypes = [vp]
-    L.s2d_destroy.restype = None
-    L.s2d_set_target.argtypes = [vp, vp]
-    L.s2d_set_target_synthetic.argtypes = [vp]
-    L.s2d_init_splats.argtypes = [vp]
-    L.s2d_set_splats.argtypes = [vp, vp]
-    L.s2d_get_splats.argtypes = [vp, vp]
-    L.s2d_set_adam.argtypes = [vp, vp, C.c_float, C.c_float, i32]
-    L.s2d_get_adam.argtypes = [vp, vp, vp, vp, vp]
-    L.s2d_forward.argtypes = [vp]
-    L.s2d_get_image.argtypes = [vp, vp]
-    L.s2d_backward.argtypes = [vp, u32]
-    L.s2d_get_grads.argtypes = [vp, vp]
-    L.s2d_adam_step.argtypes = [vp, u32]
-    L.s2d_step.argtypes = [vp, i32, u32, vp]
-    L.s2d_get_mse.argtypes = [vp, vp]
-    L.s2d_bind_grads_device.argtypes = [vp, vp]
-    L.s2d_grads_device_ptr.argtypes = [vp]
-    L.s2d_grads_device_ptr.restype = vp
-    L.s2d_get_sqerr_trace.argtypes = [vp, i32, i32, vp]
-    L.s2d_synchronize.argtypes = [vp]
-    L.s2d_get_stats.argtypes = [vp, C.POINTER(_Stats)]
-    L.s2d_get_rebuild_count.argtypes = [vp, vp]
-    L.s2d_last_error.argtypes = [vp]
-    L.s2d_last_error.restype = C.c_char_p
-    L.s2d_test_sincos.argtypes = [i32, vp, i32, vp, vp]
-    L.s2d_test_sort_pairs.argtypes = [i32, vp, vp, i64, i32]
-    L.s2d_test_exclusive_scan.argtypes = [i32, vp, i64, vp]
-    L.s2d_debug_get_tile_lists.argtypes = [vp, vp, vp, vp, i64, vp, i64]
-    L.s2d_halo_masks.argtypes = [vp, i32, vp, C.c_float, vp]
-    L.s2d_halo_commit.argtypes = [vp, vp, i32, i32]
-    L.s2d_rows_gather.argtypes = [vp, i32, vp, i32, vp]
-    L.s2d_rows_scatter.argtypes = [vp, i32, vp, i32, vp]
-    L.s2d_grads_combine.argtypes = [vp, vp, i32, vp, i32, vp]
+    ab = path != _build.LIB_PATH  # an A/B build of an older ABI may lack newer entry points (tools/gpu_ab.py)
+
+    def sig(name, argtypes=None, restype=None):
+        if ab and not hasattr(L, name):
+            return
+        f = getattr(L, name)
+        if argtypes is not None:
+            f.argtypes = argtypes
+        if restype is not None:
+            f.restype = restype
+
+    sig("s2d_abi_version", restype=C.c_int)
+    sig("s2d_create", [C.POINTER(_Config), C.POINTER(vp)])
+    sig("s2d_destroy", [vp])
+    if hasattr(L, "s2d_destroy"):
+        L.s2d_destroy.restype = None
+    sig("s2d_set_target", [vp, vp])
+    sig("s2d_set_target_synthetic", [vp])
+    sig("s2d_init_splats", [vp])
+    sig("s2d_set_splats", [vp, vp])
+    sig("s2d_get_splats", [vp, vp])
+    sig("s2d_set_adam", [vp, vp, C.c_float, C.c_float, i32])
+    sig("s2d_get_adam", [vp, vp, vp, vp, vp])
+    sig("s2d_forward", [vp])
+    sig("s2d_get_image", [vp, vp])
+    sig("s2d_backward", [vp, u32])
+    sig("s2d_forward_backward", [vp, u32])
+    sig("s2d_get_grads", [vp, vp])
+    sig("s2d_adam_step", [vp, u32])
+    sig("s2d_step", [vp, i32, u32, vp])
+    sig("s2d_get_mse", [vp, vp])
+    sig("s2d_bind_grads_device", [vp, vp])
+    sig("s2d_grads_device_ptr", [vp], restype=vp)
+    sig("s2d_get_sqerr_trace", [vp, i32, i32, vp])
+    sig("s2d_synchronize", [vp])
+    sig("s2d_get_stats", [vp, C.POINTER(_Stats)])
+    sig("s2d_get_rebuild_count", [vp, vp])
+    sig("s2d_last_error", [vp], restype=C.c_char_p)
+    sig("s2d_test_sincos", [i32, vp, i32, vp, vp])
+    sig("s2d_test_sort_pairs", [i32, vp, vp, i64, i32])
+    sig("s2d_test_exclusive_scan", [i32, vp, i64, vp])
+    sig("s2d_debug_get_tile_lists", [vp, vp, vp, vp, i64, vp, i64])
+    sig("s2d_halo_masks", [vp, i32, vp, C.c_float, vp])
+    sig("s2d_halo_commit", [vp, vp, i32, i32])
+    sig("s2d_rows_gather", [vp, i32, vp, i32, vp])
+    sig("s2d_rows_scatter", [vp, i32, vp, i32, vp])
+    sig("s2d_grads_combine", [vp, vp, i32, vp, i32, vp])
     if path == _build.LIB_PATH:
         _lib = L
     return L
@@ -241,6 +252,12 @@ class Trainer:
             skip_opacity_grad = self.lean_backward and not self.optimize_opacity
         self._ck(self.L.s2d_backward(self._h, S2D_BWD_SKIP_OPACITY_GRAD if skip_opacity_grad else 0))
 
+    def forward_backward(self, skip_opacity_grad=None):
+        """forward() + backward() in one launch per tile (same results); flags as backward()."""
+        if skip_opacity_grad is None:
+            skip_opacity_grad = self.lean_backward and not self.optimize_opacity
+        self._ck(self.L.s2d_forward_backward(self._h, S2D_BWD_SKIP_OPACITY_GRAD if skip_opacity_grad else 0))
+
     def get_grads(self):
         a = np.zeros(self.n, dtype=SPLAT_DTYPE)
         self._ck(self.L.s2d_get_grads(self._h, _p(a)))
@@ -300,7 +317,6 @@ class Trainer:
         self._ck(self.L.s2d_get_stats(self._h, C.byref(s)))
         out = {k: getattr(s, k) for k, _ in _Stats._fields_}
         out["bwd_lane_hist"] = list(s.bwd_lane_hist)
-        out["phase_cycles"] = list(s.phase_cycles)
         return out
 
     def rebuild_count(self):

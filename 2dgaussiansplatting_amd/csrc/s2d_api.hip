@@ -89,6 +89,7 @@ struct s2d_ctx {
     bool have_target = false;
     bool have_forward = false;
     bool have_backward = false;
+    bool sqerr_deferred = false; // the squared-error reduction of the last backward pass rides on the next Adam launch
     int last_sqerr_slot = -1;
     char err[512] = {0};
 };
@@ -194,26 +195,45 @@ int rebuild_lists(s2d_ctx* c)
     return S2D_OK;
 }
 
-// Forward pass on lists that are known to cover the current parameters.
-int launch_forward(s2d_ctx* c, bool optimistic)
+// First raster launch of an iteration, on lists believed (optimistic) or known to cover the current parameters:
+// the forward kernel alone, or the fused forward + backward kernel.
+struct RasterJob {
+    bool fused = false;        // forward + backward walk in one launch
+    bool need_opacity_grad = true;
+    bool write_image = true;   // fused only: store image0 (nothing but s2d_get_image reads it)
+};
+
+int launch_raster(s2d_ctx* c, bool optimistic, const RasterJob& job)
 {
     const int abort_stamp = optimistic ? c->check_seq : 0;
-    S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->half_images, c->d_wave_masks,
-                                     c->g, c->d_status, abort_stamp, c->iterations, c->d_counters, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) != 0,
-                                     (c->cfg.flags & S2D_CFG_EXACT_EXP) != 0, c->stream));
+    const bool count = (c->cfg.flags & S2D_CFG_COUNT_PAIRS) != 0, exact = (c->cfg.flags & S2D_CFG_EXACT_EXP) != 0;
+    if (!job.fused) {
+        S2D_HIP(c, launch_raster_forward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->half_images, c->d_wave_masks,
+                                         c->g, c->d_status, abort_stamp, c->iterations, c->d_counters, count, exact, c->stream));
+        return S2D_OK;
+    }
+    DetGather dg{};
+    if (c->deterministic) {
+        c->det_epoch++; // a fresh stamp per backward pass (slots of earlier passes become invalid)
+        dg = DetGather{c->d_rects, c->d_offsets, c->d_counts, c->d_det_data, c->d_det_stamp, c->det_epoch, c->n};
+    }
+    S2D_HIP(c, launch_raster_fused(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->half_images, c->d_wave_masks,
+                                   c->d_grads, c->d_tile_sqerr, c->g, job.need_opacity_grad, c->deterministic ? &dg : nullptr,
+                                   c->d_status, abort_stamp, c->iterations, job.write_image, exact, c->stream));
     return S2D_OK;
 }
 
-// Project the splats, make sure the tile lists cover them, run the forward raster.
+// Project the splats, make sure the tile lists cover them, run the forward raster (or the fused forward + backward).
 //
 // Steady state (lists re-used): the projection of the current parameters and the containment check were produced by
 // the Adam kernel of the previous iteration, which stamps a device word and a host-mapped word with the check's
-// sequence number if some splat left its binned rectangle.  The forward kernel is launched OPTIMISTICALLY: it
+// sequence number if some splat left its binned rectangle.  The raster kernel is launched OPTIMISTICALLY: it
 // compares the device word with that sequence number and does nothing on a match, and the host reads its word only
-// after the launch (waiting for the CHECKING kernel, not the forward kernel), so the GPU never waits for the host and
-// no flag has to be copied or cleared.  If the check failed the lists are rebuilt and the forward kernel is
-// launched again.
-int queue_forward(s2d_ctx* c)
+// after the launch (waiting for the CHECKING kernel, not the raster kernel), so the GPU never waits for the host and
+// no flag has to be copied or cleared.  If the check failed the lists are rebuilt and the raster kernel is
+// launched again.  (In deterministic mode the gather pass queued behind a voided fused launch adds nothing: the
+// slots carry no stamp of that pass.)
+int queue_raster(s2d_ctx* c, const RasterJob& job)
 {
     if (!c->have_target) return fail(c, S2D_E_STATE, "no target image set (s2d_set_target)");
     const bool scheduled = !c->lists_valid || c->rebin_interval <= 1 || c->since_rebin >= c->rebin_interval;
@@ -226,8 +246,8 @@ int queue_forward(s2d_ctx* c)
             S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
             c->proj_fresh = true;
         }
-        if (int rc = launch_forward(c, true)) return rc;
-        S2D_HIP(c, hipEventSynchronize(c->ev_flag)); // the checking kernel, not the forward kernel
+        if (int rc = launch_raster(c, true, job)) return rc;
+        S2D_HIP(c, hipEventSynchronize(c->ev_flag)); // the checking kernel, not the raster kernel
         rebuild = *(volatile int*)c->h_rebin_stamp == c->check_seq;
     }
     if (rebuild) {
@@ -236,17 +256,33 @@ int queue_forward(s2d_ctx* c)
         if (int rc = rebuild_lists(c)) return rc;
         c->proj_fresh = true;
         c->check_seq++; // the new lists cover the current parameters: a stamp that asked for them matches nothing now
-        if (int rc = launch_forward(c, false)) return rc;
+        if (int rc = launch_raster(c, false, job)) return rc;
     }
     c->have_forward = true;
     c->have_backward = false;
     return S2D_OK;
 }
 
+int queue_forward(s2d_ctx* c) { return queue_raster(c, RasterJob{}); }
+
+// Sum of the tile errors of the backward pass just queued -> ring slot of this iteration.  defer: leave it to the Adam
+// launch that the caller queues next (s2d_step), whose first workgroups do it on the way (one dispatch less).
+int queue_sqerr(s2d_ctx* c, bool defer = false)
+{
+    const int slot = c->iterations % c->trace_cap;
+    c->last_sqerr_slot = slot;
+    c->have_backward = true;
+    // (worth it only when the Adam launch has a workgroup per chunk: a 4-workgroup launch would walk 16 chunks each)
+    c->sqerr_deferred = defer && (c->n + 255) / 256 >= kSqerrChunks;
+    if (c->sqerr_deferred) return S2D_OK;
+    S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->d_tile_sqerr + c->g.num_tiles,
+                                     c->d_status, c->iterations, c->stream));
+    return S2D_OK;
+}
+
 int queue_backward(s2d_ctx* c, bool need_opacity_grad)
 {
     if (!c->have_forward) return fail(c, S2D_E_STATE, "s2d_backward needs s2d_forward on the current parameters");
-    const int slot = c->iterations % c->trace_cap;
     DetGather dg{};
     if (c->deterministic) {
         c->det_epoch++; // a fresh stamp per backward pass (slots of earlier passes become invalid)
@@ -257,11 +293,23 @@ int queue_backward(s2d_ctx* c, bool need_opacity_grad)
                                       c->d_tile_sqerr, c->g, need_opacity_grad, c->deterministic ? &dg : nullptr,
                                       c->d_status, c->iterations, c->d_counters, (c->cfg.flags & S2D_CFG_COUNT_PAIRS) != 0,
                                       (c->cfg.flags & S2D_CFG_EXACT_EXP) != 0, c->stream));
-    S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + slot, c->d_tile_sqerr + c->g.num_tiles,
-                                     c->d_status, c->iterations, c->stream));
-    c->last_sqerr_slot = slot;
-    c->have_backward = true;
-    return S2D_OK;
+    return queue_sqerr(c);
+}
+
+// Forward + backward (+ squared error) of the current parameters through the fused kernel.  Pair counting is a
+// property of the separate kernels only, so a counting context takes those.
+int queue_forward_backward(s2d_ctx* c, bool need_opacity_grad, bool write_image, bool defer_sqerr = false)
+{
+    if (c->cfg.flags & S2D_CFG_COUNT_PAIRS) {
+        if (int rc = queue_forward(c)) return rc;
+        return queue_backward(c, need_opacity_grad);
+    }
+    RasterJob job;
+    job.fused = true;
+    job.need_opacity_grad = need_opacity_grad;
+    job.write_image = write_image;
+    if (int rc = queue_raster(c, job)) return rc;
+    return queue_sqerr(c, defer_sqerr);
 }
 
 int queue_adam(s2d_ctx* c, uint32_t flags)
@@ -276,7 +324,12 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
                            c->lr,
                            ((flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0) | ((c->cfg.flags & S2D_CFG_ADAM_FP32) ? 2 : 0),
                            c->iterations, c->d_status,
-                           fuse ? c->d_proj : nullptr, c->d_rects, c->check_seq, c->h_rebin_stamp, c->stream));
+                           fuse ? c->d_proj : nullptr, c->d_rects, c->check_seq, c->h_rebin_stamp,
+                           c->sqerr_deferred ? SqerrJob{c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + c->last_sqerr_slot,
+                                                        c->d_tile_sqerr + c->g.num_tiles}
+                                             : SqerrJob{nullptr, 0, nullptr, nullptr},
+                           c->stream));
+    c->sqerr_deferred = false;
     if (fuse) S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
     c->proj_fresh = fuse;
     c->iterations++; // main.cpp:809
@@ -558,6 +611,13 @@ int s2d_get_image(s2d_ctx* c, float* rgba32f)
     return S2D_OK;
 }
 
+int s2d_forward_backward(s2d_ctx* c, uint32_t flags)
+{
+    if (!c) return S2D_E_INVALID;
+    if (int rc = use_device(c)) return rc;
+    return queue_forward_backward(c, !(flags & S2D_BWD_SKIP_OPACITY_GRAD), true);
+}
+
 int s2d_backward(s2d_ctx* c, uint32_t flags)
 {
     if (!c) return S2D_E_INVALID;
@@ -593,8 +653,9 @@ int s2d_step(s2d_ctx* c, int32_t iters, uint32_t flags, double* mse_out)
         const int chunk = std::min(iters - done, c->trace_cap);
         const int first_iter = c->iterations;
         for (int k = 0; k < chunk; k++) {
-            if (int rc = queue_forward(c)) return rc;
-            if (int rc = queue_backward(c, (flags & S2D_STEP_OPTIMIZE_OPACITY) != 0)) return rc;
+            // image0 is stored by the last iteration of the call only: nothing else could observe the others
+            const bool last = done + k + 1 == iters;
+            if (int rc = queue_forward_backward(c, (flags & S2D_STEP_OPTIMIZE_OPACITY) != 0, last, true)) return rc;
             if (int rc = queue_adam(c, flags)) return rc;
         }
         if (mse_out) {
@@ -757,7 +818,6 @@ int s2d_get_stats(s2d_ctx* c, s2d_stats* out)
     for (int k = 0; k < 65; k++) out->bwd_lane_hist[k] = pc.bwd_lane_hist[k];
     out->fwd_staged_hit = pc.fwd_staged_hit;
     out->fwd_rows_hit = pc.fwd_rows_hit;
-    for (int k = 0; k < 16; k++) out->phase_cycles[k] = pc.phase_cycles[k];
     out->iterations = c->iterations;
     out->first_nonfinite_iteration = c->h_status->nonfinite ? c->h_status->first_nonfinite_iter : -1;
     return S2D_OK;

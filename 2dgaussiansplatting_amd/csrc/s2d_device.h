@@ -41,10 +41,6 @@ struct PairCounters {
     unsigned long long bwd_lane_hist[65]; // executed (wave, entry) pairs by number of active lanes
     unsigned long long fwd_staged_hit;    // staged entries with at least one pixel of the tile inside their ranges
     unsigned long long fwd_rows_hit;      // (staged entry, tile row) pairs with a non-empty column range
-    // -DS2D_PHASE_TIMING builds only: shader-clock cycles summed over waves.  [0..3] forward: staging, barrier after
-    // staging, blend loop, barrier after the loop; [6] whole kernel, [7] executed (wave, entry) pairs.  [8..12] backward:
-    // staging, barrier, blend loop, barrier, flush; [14] whole kernel, [15] executed (wave, entry) pairs.
-    unsigned long long phase_cycles[16];
 };
 
 // Device-resident status word(s), written by kernels, read by the host at synchronisation points.
@@ -175,6 +171,12 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
                                   const unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
                                   bool need_opacity_grad, const DetGather* dg, const DeviceStatus* status, int iteration,
                                   PairCounters* counters, bool count, bool exact_exp, hipStream_t stream);
+// Forward + backward walk of every tile in one launch (same results as the two launches above).
+hipError_t launch_raster_fused(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
+                               const void* image_ref, bool half_images, unsigned long long* wave_masks, float* grads,
+                               double* tile_sqerr, Geometry g, bool need_opacity_grad, const DetGather* dg,
+                               const DeviceStatus* status, int abort_stamp, int iteration, bool write_image, bool exact_exp,
+                               hipStream_t stream);
 // Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
 // slab ownership (s2d_halo.hip): `held` == nullptr means every splat is held (single rank, or replicated state)
 hipError_t launch_halo_masks(const float* splats, const uint8_t* held, int n, int world, const int* row_bounds, float margin,
@@ -187,7 +189,64 @@ hipError_t launch_rows_scatter(float* base, int w, const int* ids, int count, in
 hipError_t launch_grads_combine(float* grads, const int* rows, int n_rows, const int* src, int world, const float* recv,
                                 int n, hipStream_t stream);
 // scratch: kSqerrScratchDoubles doubles, zero before the first launch
-constexpr int kSqerrScratchDoubles = 64 + 1;
+constexpr int kSqerrChunks = 64;
+constexpr int kSqerrScratchDoubles = kSqerrChunks + 1;
+
+#if defined(__HIPCC__)
+__device__ __forceinline__ double block_sum_256(double v, double* s)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const double r = ((s[0] + s[1]) + s[2]) + s[3];
+    __syncthreads(); // s may be written again by the caller's next sum
+    return r;
+}
+
+// Sum of the per-tile squared errors in a FIXED order (a deterministic MSE trace, main.cpp:796-805), shared between
+// workgroups: the tiles are cut into kSqerrChunks contiguous chunks; the calling 256-thread workgroup reduces chunks
+// first_chunk, first_chunk + chunk_stride, ... into scratch[chunk]; the workgroup that completes the last chunk (a
+// ticket counter behind the partials) adds the kSqerrChunks partials, again in a fixed order, writes *out and re-arms
+// the counter.  The result does not depend on how many workgroups share the chunks.  Every thread of the workgroup
+// must call this.
+__device__ __forceinline__ void sqerr_reduce(const double* __restrict__ tile_sqerr, int num_tiles, double* __restrict__ out,
+                                             double* scratch, int first_chunk, int chunk_stride)
+{
+    __shared__ double s[4];
+    __shared__ bool last;
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(scratch + kSqerrChunks);
+    const int chunk = (num_tiles + kSqerrChunks - 1) / kSqerrChunks;
+    unsigned long long mine = 0;
+    for (int b = first_chunk; b < kSqerrChunks; b += chunk_stride, mine++) {
+        const int beg = b * chunk, end = min(beg + chunk, num_tiles);
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        for (int i = beg + (int)threadIdx.x; i < end; i += 1024) {
+            a0 += tile_sqerr[i];
+            if (i + 256 < end) a1 += tile_sqerr[i + 256];
+            if (i + 512 < end) a2 += tile_sqerr[i + 512];
+            if (i + 768 < end) a3 += tile_sqerr[i + 768];
+        }
+        const double part = block_sum_256((a0 + a1) + (a2 + a3), s);
+        if (threadIdx.x == 0) __hip_atomic_store(scratch + b, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = mine != 0 && atomicAdd(ticket, mine) + mine == (unsigned long long)kSqerrChunks;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    const double p = threadIdx.x < kSqerrChunks
+                         ? __hip_atomic_load(scratch + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                         : 0.0;
+    const double total = block_sum_256(p, s);
+    if (threadIdx.x == 0) {
+        *out = total;
+        *ticket = 0ull;
+    }
+}
+#endif
 hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, double* scratch,
                                  const DeviceStatus* status, int iteration, hipStream_t stream);
 
@@ -195,10 +254,18 @@ hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double
 hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream);
 // proj != nullptr: also project the UPDATED splat for the next iteration and check it against rects[]
 // (what project_kernel mode 1 would do), raising status->rebin_needed.
+// sq.tile_sqerr != nullptr: the launch's first workgroups also reduce the per-tile squared errors of the backward pass
+// queued before it into *sq.out (sqerr_reduce), which saves the separate finalize dispatch.
+struct SqerrJob {
+    const double* tile_sqerr;
+    int num_tiles;
+    double* out;
+    double* scratch;
+};
 hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t* held_ids, const uint32_t* held_count, int n,
                        Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
-                       const TileRect* rects, int check_stamp, int* host_stamp, hipStream_t stream);
+                       const TileRect* rects, int check_stamp, int* host_stamp, SqerrJob sq, hipStream_t stream);
 hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, hipStream_t stream);
 // RGBA32F <-> 4 x fp16 (round to nearest even) for images that cross the boundary as floats
 hipError_t launch_convert_f32_to_f16(const float4* src, void* dst, size_t pixels, hipStream_t stream);

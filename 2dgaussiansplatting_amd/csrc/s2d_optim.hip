@@ -37,14 +37,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
                                                    float beta2t, float lr, int optimize_opacity, int iteration,
                                                    DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
                                                    const TileRect* __restrict__ rects, int check_stamp,
-                                                   int* __restrict__ host_stamp)
+                                                   int* __restrict__ host_stamp, SqerrJob sq)
 {
     const int W = g.W, H = g.H;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
     // The reference abort()s at the first non-finite parameter (main.cpp:752-785): later iterations do nothing.
     // (Strictly earlier: blocks of the detecting launch itself, which stores `iteration`, must all finish their work.)
     if (status->first_nonfinite_iter < iteration) return;
+    // MSE of the iteration (main.cpp:796-805) from the tile errors the backward pass left, by this launch's first
+    // workgroups (block-uniform branch: all 256 threads take it together)
+    if (sq.tile_sqerr != nullptr && blockIdx.x < (unsigned)kSqerrChunks)
+        sqerr_reduce(sq.tile_sqerr, sq.num_tiles, sq.out, sq.scratch, (int)blockIdx.x, min((int)gridDim.x, kSqerrChunks));
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
     if (held_ids) { // slab ownership (s2d_halo.hip): only the splats this rank holds, from their compact list
         if ((uint32_t)i >= *held_count) return;
         i = (int)held_ids[i];
@@ -163,11 +167,11 @@ hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, 
 hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t* held_ids, const uint32_t* held_count,
                        int n, Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
-                       const TileRect* rects, int check_stamp, int* host_stamp, hipStream_t stream)
+                       const TileRect* rects, int check_stamp, int* host_stamp, SqerrJob sq, hipStream_t stream)
 {
-    if (n <= 0) return hipSuccess;
+    if (n <= 0) return hipSuccess; // (callers queue the standalone squared-error reduction themselves when n == 0)
     hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, held_ids, held_count, n, g, beta1t,
-                       beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp);
+                       beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, sq);
     return hipGetLastError();
 }
 

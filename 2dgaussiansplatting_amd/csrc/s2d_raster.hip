@@ -46,17 +46,6 @@ __device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v,
     return ((unsigned long long)hi << 32) | lo;
 }
 
-// Diagnostic build only (-DS2D_PHASE_TIMING, tools/build_timing_lib.py; never the shipped library): every wave adds
-// the shader-clock cycles it spends in each phase of the batch loop to PairCounters::phase_cycles, which tells
-// where the waves of the raster kernels wait (staging latency, barriers, the blend loop, the flush).
-#ifdef S2D_PHASE_TIMING
-#define S2D_T(var) const long long var = (long long)clock64()
-#define S2D_TACC(slot, a, b) ph[slot] += (unsigned long long)((b) - (a))
-#else
-#define S2D_T(var)
-#define S2D_TACC(slot, a, b)
-#endif
-
 // Framebuffer / target pixel in HBM: RGBA32F (the reference's Image2DRGBA32, 16 B) or, with S2D_CFG_FP16_IMAGES,
 // four IEEE halves (8 B, round-to-nearest-even on store).  Arithmetic is fp32 either way.
 template <bool HALF>
@@ -158,81 +147,86 @@ __device__ __forceinline__ float gauss_of(float d2, bool* nonzero)
     return gauss_pow8(d2, nonzero);
 }
 
-template <bool COUNT, bool HALF, bool EXACT>
-__global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __restrict__ tile_off,
-                                                             const uint32_t* __restrict__ list,
-                                                             const ProjRec* __restrict__ proj,
-                                                             void* __restrict__ image0,
-                                                             unsigned long long* __restrict__ wave_masks, Geometry g,
-                                                             const DeviceStatus* __restrict__ status, int abort_stamp,
-                                                             int iteration, PairCounters* __restrict__ counters)
+// What a thread needs to know about its pixel and its place in the workgroup.
+struct TileCtx {
+    int tile, tx, ty;   // tile index (local to the slab), tile column, GLOBAL tile row
+    int tid, lane, w;   // thread, lane, wave within the workgroup
+    int x, y;           // pixel
+    bool inside;        // pixel inside the image and the slab
+    f2 pxy;             // pixel centre, main.cpp:523
+};
+
+__device__ __forceinline__ TileCtx tile_ctx(int tile, const Geometry& g)
 {
-    // per-entry record, three 16-B rows at one LDS address (one address register for the blend loop's reads):
-    //   [0] pos.x, pos.y, a, b   [1] b, d, col_r, col_g   [2] col_b, opacity, -, -
-    // (b twice: (a,b) and (b,d) are the two columns of inv_cov)
-    __shared__ float4 s_rec[B][3];
-    __shared__ unsigned long long s_mask[4 * B]; // [wave][entry]
-
-    // Optimistic launch: the host queues this kernel before it has seen the containment flag the previous Adam
-    // (or projection) kernel produced.  If some splat left its binned rectangle the lists are stale: do nothing;
-    // the host rebuilds them and launches again.  The flag is final before this kernel starts (stream order).
-    // abort_stamp 0: lists known to be current.  A parameter that went non-finite in an EARLIER iteration stops the
-    // run where the reference abort()s (main.cpp:752-785): every later kernel of the queue does nothing.
-    if ((abort_stamp != 0 && status->rebin_needed == abort_stamp) || status->first_nonfinite_iter < iteration) return;
-    const int tile = tile_of_block(blockIdx.x, g);
-    if (tile < 0) return;
-    const int tx = tile % g.tiles_x;
-    const int ty = tile / g.tiles_x + g.trow0;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    TileCtx c;
+    c.tile = tile;
+    c.tx = tile % g.tiles_x;
+    c.ty = tile / g.tiles_x + g.trow0;
+    c.tid = threadIdx.x;
+    c.lane = c.tid & 63;
+    c.w = c.tid >> 6;
     int lx, ly;
-    pixel_of_thread(tid, &lx, &ly);
-    const int x = tx * kTile + lx;
-    const int y = ty * kTile + ly;
-    const bool inside = x < g.W && y < g.row_end;
-    const f2 pxy = mk2((float)x + 0.5f, (float)y + 0.5f);   // main.cpp:523
+    pixel_of_thread(c.tid, &lx, &ly);
+    c.x = c.tx * kTile + lx;
+    c.y = c.ty * kTile + ly;
+    c.inside = c.x < g.W && c.y < g.row_end;
+    c.pxy = mk2((float)c.x + 0.5f, (float)c.y + 0.5f);
+    return c;
+}
 
-    f2 crg = mk2(0.0f, 0.0f);                               // main.cpp:414: (0,0,0,1)
-    float cb = 0.0f, T = 1.0f;
+// LDS of the forward walk: per-entry record, three 16-B rows at one LDS address (one address register for the blend
+// loop's reads):  [0] pos.x, pos.y, a, b   [1] b, d, col_r, col_g   [2] col_b, opacity, -, -
+// (b twice: (a,b) and (b,d) are the two columns of inv_cov)
+struct FwdShared {
+    float4 rec[B][3];
+    unsigned long long mask[4 * B]; // [wave][entry]
+};
+
+// One tile's forward walk (main.cpp:419-536 for its pixels): leaves the final colour of this thread's pixel in
+// (crg, cb) and the lane masks of every staged pair in wave_masks.
+template <bool COUNT, bool EXACT>
+__device__ __forceinline__ void forward_tile(FwdShared& s, const TileCtx& c, const uint32_t* __restrict__ tile_off,
+                                             const uint32_t* __restrict__ list, const ProjRec* __restrict__ proj,
+                                             unsigned long long* __restrict__ wave_masks, const Geometry& g,
+                                             PairCounters* __restrict__ counters, f2& crg, float& cb)
+{
+    const int tid = c.tid, lane = c.lane, w = c.w;
+    const f2 pxy = c.pxy;
+    crg = mk2(0.0f, 0.0f);                                  // main.cpp:414: (0,0,0,1)
+    cb = 0.0f;
+    float T = 1.0f;
     // Pixels still above the throughput cut-off (main.cpp:520), as ONE wave-uniform 64-bit mask in scalar registers.
     // (A per-lane bool here costs ~15 scalar instructions per blended entry to merge with exec, and the CU's
     // single scalar unit -- not the SIMDs -- then bounds the loop; measured, profiles/r01/valu_rates.txt.)
-    unsigned long long alive_mask = __ballot(inside);
+    unsigned long long alive_mask = __ballot(c.inside);
     unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0, n_rows_hit = 0, n_staged_hit = 0;
-#ifdef S2D_PHASE_TIMING
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long n_exec_t = 0;
-#endif
-    S2D_T(tk0);
 
-    const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
+    const uint32_t beg = tile_off[c.tile], end = tile_off[c.tile + 1];
     const int se = tid >> 2, sub = tid & 3;
     for (uint32_t base = beg; base < end; base += B) {
         const int cnt = (int)min((uint32_t)B, end - base);
-        S2D_T(t0);
         if (se < cnt) {
             const ProjRec* r = proj + list[base + se];
             const float4 q0 = r->q0, q1 = r->q1, q2 = r->q2;
-            const int rows_hit = stage_masks(reinterpret_cast<uint32_t*>(s_mask), se, sub, q0, q1, __float_as_int(q2.y),
-                                             __float_as_int(q2.z), ty * kTile, tx * kTile, g.W, g.row_end);
+            const int rows_hit = stage_masks(reinterpret_cast<uint32_t*>(s.mask), se, sub, q0, q1, __float_as_int(q2.y),
+                                             __float_as_int(q2.z), c.ty * kTile, c.tx * kTile, g.W, g.row_end);
             if (COUNT) {
                 n_rows_hit += rows_hit;
                 const int entry_rows = rows_hit + __shfl_xor(rows_hit, 1) + __shfl_xor(rows_hit, 2); // the entry's 4 threads
                 n_staged_hit += (sub == 0 && entry_rows > 0) ? 1 : 0;
             }
             if (sub == 0) {
-                s_rec[se][0] = q0;
-                s_rec[se][1] = make_float4(q0.w, q1.x, q1.y, q1.z);
-                s_rec[se][2] = make_float4(q1.w, q2.x, 0.0f, 0.0f);
+                s.rec[se][0] = q0;
+                s.rec[se][1] = make_float4(q0.w, q1.x, q1.y, q1.z);
+                s.rec[se][2] = make_float4(q1.w, q2.x, 0.0f, 0.0f);
             }
         }
-        S2D_T(t1);
         __syncthreads();
-        S2D_T(t2);
-        // keep the lane masks for the backward pass, which walks exactly these batches (32 B per staged pair)
-        if (se < cnt) wave_masks[(size_t)(base + se) * 4 + sub] = s_mask[sub * B + se];
+        // keep the lane masks for the backward walk, which goes through exactly these batches (32 B per staged pair)
+        if (se < cnt) wave_masks[(size_t)(base + se) * 4 + sub] = s.mask[sub * B + se];
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
         if (alive_mask != 0ull || COUNT) {
-            const unsigned long long my_mask = (lane < cnt) ? s_mask[w * B + lane] : 0ull;
+            const unsigned long long my_mask = (lane < cnt) ? s.mask[w * B + lane] : 0ull;
             unsigned long long cand = __ballot(my_mask != 0ull); // entries that touch this wave's block at all
             while (cand != 0ull) {
                 const int e = __builtin_ctzll(cand);
@@ -242,12 +236,9 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                 const unsigned long long act = wm & alive_mask; // visited (main.cpp:511-514) and not cut off (:520)
                 if (act == 0ull) continue;
                 if (COUNT) n_exec += (lane == 0);
-#ifdef S2D_PHASE_TIMING
-                n_exec_t++;
-#endif
                 // Branch-free body: lanes outside `act` run the same instructions with alpha forced to 0, which
                 // makes c += (T*c)*0 and T *= 1 exact no-ops.  The scalar mask itself is the select predicate.
-                const float4 q0 = s_rec[e][0], q1 = s_rec[e][1], q2 = s_rec[e][2];
+                const float4 q0 = s.rec[e][0], q1 = s.rec[e][1], q2 = s.rec[e][2];
                 const f2 v = pxy - mk2(q0.x, q0.y);                          // main.cpp:523-524
                 const f2 m = mk2(q0.z, q0.w) * v.x + mk2(q1.x, q1.y) * v.y;  // inv_cov * v: (a vx + b vy, b vx + d vy)
                 const f2 vm = v * m;
@@ -262,24 +253,8 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
                 if (COUNT) n_act += (act >> lane) & 1ull;
             }
         }
-        S2D_T(t3);
-        const int any_alive = __syncthreads_or(alive_mask != 0ull ? 1 : 0);
-        S2D_T(t4);
-        S2D_TACC(0, t0, t1);
-        S2D_TACC(1, t1, t2);
-        S2D_TACC(2, t2, t3);
-        S2D_TACC(3, t3, t4);
-        if (!any_alive) break;
+        if (!__syncthreads_or(alive_mask != 0ull ? 1 : 0)) break; // every pixel of the tile saturated: retire it
     }
-#ifdef S2D_PHASE_TIMING
-    if (lane == 0) {
-        S2D_T(tk1);
-        for (int k = 0; k < 4; k++) atomicAdd(&counters->phase_cycles[k], ph[k]);
-        atomicAdd(&counters->phase_cycles[6], (unsigned long long)(tk1 - tk0));
-        atomicAdd(&counters->phase_cycles[7], n_exec_t);
-    }
-#endif
-    if (inside) store_pixel<HALF>(image0, (size_t)y * g.W + x, make_float4(crg.x, crg.y, cb, 1.0f)); // .w reset, main.cpp:543-546
     if (COUNT) {
         atomicAdd(&counters->fwd_visited, n_vis);
         atomicAdd(&counters->fwd_active, n_act);
@@ -288,6 +263,36 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
         atomicAdd(&counters->fwd_rows_hit, n_rows_hit);
         atomicAdd(&counters->fwd_staged_hit, n_staged_hit);
     }
+}
+
+// Optimistic launch: the host queues the first raster kernel of an iteration before it has seen the containment flag
+// the previous Adam (or projection) kernel produced.  If some splat left its binned rectangle the lists are stale:
+// do nothing; the host rebuilds them and launches again.  The flag is final before the kernel starts (stream order).
+// abort_stamp 0: lists known to be current.  A parameter that went non-finite in an EARLIER iteration stops the
+// run where the reference abort()s (main.cpp:752-785): every later kernel of the queue does nothing.
+__device__ __forceinline__ bool launch_is_void(const DeviceStatus* status, int abort_stamp, int iteration)
+{
+    return (abort_stamp != 0 && status->rebin_needed == abort_stamp) || status->first_nonfinite_iter < iteration;
+}
+
+template <bool COUNT, bool HALF, bool EXACT>
+__global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __restrict__ tile_off,
+                                                             const uint32_t* __restrict__ list,
+                                                             const ProjRec* __restrict__ proj,
+                                                             void* __restrict__ image0,
+                                                             unsigned long long* __restrict__ wave_masks, Geometry g,
+                                                             const DeviceStatus* __restrict__ status, int abort_stamp,
+                                                             int iteration, PairCounters* __restrict__ counters)
+{
+    __shared__ FwdShared s;
+    if (launch_is_void(status, abort_stamp, iteration)) return;
+    const int tile = tile_of_block(blockIdx.x, g);
+    if (tile < 0) return;
+    const TileCtx c = tile_ctx(tile, g);
+    f2 crg;
+    float cb;
+    forward_tile<COUNT, EXACT>(s, c, tile_off, list, proj, wave_masks, g, counters, crg, cb);
+    if (c.inside) store_pixel<HALF>(image0, (size_t)c.y * g.W + c.x, make_float4(crg.x, crg.y, cb, 1.0f)); // .w reset, main.cpp:543-546
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -396,55 +401,40 @@ struct DetSlots {
     uint32_t now;             // iteration + 1
 };
 
-template <bool COUNT, bool NEED_OP, bool HALF, bool DET, bool EXACT>
-__global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
-                                                              const uint32_t* __restrict__ list,
-                                                              const ProjRec* __restrict__ proj,
-                                                              const void* __restrict__ image0,
-                                                              const void* __restrict__ image_ref,
-                                                              const unsigned long long* __restrict__ wave_masks,
-                                                              float* __restrict__ grads,
-                                                              double* __restrict__ tile_sqerr, Geometry g,
-                                                              DetSlots det, const DeviceStatus* __restrict__ status,
-                                                              int iteration, PairCounters* __restrict__ counters)
-{
-    __shared__ float4 s_q0[B]; // pos.x, pos.y, a, b
-    __shared__ float4 s_q1[B]; // b, d, col_r, col_g
-    __shared__ float4 s_q2[B]; // col_b, opacity, (sx^2-sy^2)/(sx^2 sy^2), sin*cos
-    __shared__ float4 s_e0[B]; // cc, ss, 2sc, -2sc
-    __shared__ float4 s_e1[B]; // ss, cc, 1/sx^3, 1/sy^3
-    __shared__ unsigned long long s_mask[4 * B]; // [wave][entry]
-    __shared__ uint32_t s_idx[2][B];
+// LDS of the backward walk.
+template <bool DET>
+struct BwdShared {
+    float4 q0[B]; // pos.x, pos.y, a, b
+    float4 q1[B]; // b, d, col_r, col_g
+    float4 q2[B]; // col_b, opacity, (sx^2-sy^2)/(sx^2 sy^2), sin*cos
+    float4 e0[B]; // cc, ss, 2sc, cc - ss
+    float4 e1[B]; // ss, cc, 1/sx^3, 1/sy^3
+    unsigned long long mask[4 * B]; // [wave][entry]
     // Partial gradients of the batch, 9 (+3 pad) floats per entry.  Deterministic mode: one slot per wave, plain
     // stores, summed over the 4 waves in a fixed order by the flush.  Otherwise the four waves add into ONE slot
     // per entry with ds_add_f32 (eight lanes, eight addresses per wave and entry): the order of those four
     // additions is as free as the order of the global atomics that follow, and 9 KB less LDS per workgroup is
     // one to two more resident workgroups per CU.  The flush zeroes what it read.
-    constexpr int kPartWaves = DET ? 4 : 1;
-    __shared__ float4 s_part[kPartWaves][B][3];
-    __shared__ unsigned long long s_touched[4]; // bit e: wave w wrote slot e in this batch
-    __shared__ double s_red[4];
-    __shared__ __attribute__((aligned(16))) float s_xpose[4][kRedDwords]; // wave-private transpose scratch
+    float4 part[DET ? 4 : 1][B][3];
+    unsigned long long touched[4]; // bit e: wave w wrote slot e in this batch
+    double red[4];
+    __attribute__((aligned(16))) float xpose[4][kRedDwords]; // wave-private transpose scratch
+};
 
-    if (status->first_nonfinite_iter < iteration) return; // the reference abort()ed in an earlier iteration
-    const int tile = tile_of_block(blockIdx.x, g);
-    if (tile < 0) return;
-    const int tx = tile % g.tiles_x;
-    const int ty = tile / g.tiles_x + g.trow0;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    int lx, ly;
-    pixel_of_thread(tid, &lx, &ly);
-    const int x = tx * kTile + lx;
-    const int y = ty * kTile + ly;
-    const bool inside = x < g.W && y < g.row_end;
-    const f2 pxy = mk2((float)x + 0.5f, (float)y + 0.5f);
+// One tile's backward walk (main.cpp:552-711 for its pixels) from the pixel's final colour `fin` and target `ref`:
+// adds the tile's partial gradients into grads (or its deterministic slots) and stores the tile's squared error.
+template <bool COUNT, bool NEED_OP, bool DET, bool EXACT>
+__device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& c, const float4 fin, const float4 ref,
+                                              const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ list,
+                                              const ProjRec* __restrict__ proj,
+                                              const unsigned long long* __restrict__ wave_masks,
+                                              float* __restrict__ grads, double* __restrict__ tile_sqerr,
+                                              const Geometry& g, const DetSlots& det, PairCounters* __restrict__ counters)
+{
+    const int tid = c.tid, lane = c.lane, w = c.w;
+    const bool inside = c.inside;
+    const f2 pxy = c.pxy;
     const int part_slot = lane >> 3; // after wave_sum8_lds the 8-lane group holds the total of component lane >> 3
-
-    float4 fin = make_float4(0.f, 0.f, 0.f, 0.f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (inside) {
-        fin = load_pixel<HALF>(image0, (size_t)y * g.W + x);    // finalColor, main.cpp:613
-        ref = load_pixel<HALF>(image_ref, (size_t)y * g.W + x);
-    }
     const float dLr = fin.x - ref.x, dLg = fin.y - ref.y, dLb = fin.z - ref.z; // dL_dC, main.cpp:616
     const f2 dLrg = mk2(dLr, dLg), fin_rg = mk2(fin.x, fin.y);
 
@@ -454,32 +444,25 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         double e2 = inside ? (double)(ex * ex + ey * ey + ez * ez) : 0.0;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) e2 += __shfl_down(e2, d, 64);
-        if (lane == 0) s_red[w] = e2;
+        if (lane == 0) s.red[w] = e2;
     }
     if (!DET)
-        for (int i = tid; i < B * 3; i += 256) s_part[0][i / 3][i % 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < B * 3; i += 256) s.part[0][i / 3][i % 3] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    if (tid == 0) tile_sqerr[tile] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+    if (tid == 0) tile_sqerr[c.tile] = ((s.red[0] + s.red[1]) + s.red[2]) + s.red[3];
 
     f2 crg = mk2(0.0f, 0.0f);                        // image1 = (0,0,0,1), main.cpp:549
     float cb = 0.0f, T = 1.0f;
     unsigned long long alive_mask = __ballot(inside); // wave-uniform, scalar registers (see the forward kernel)
     unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0;
-#ifdef S2D_PHASE_TIMING
-    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long n_exec_t = 0;
-#endif
-    S2D_T(tk0);
 
-    const uint32_t beg = tile_off[tile], end = tile_off[tile + 1];
+    const uint32_t beg = tile_off[c.tile], end = tile_off[c.tile + 1];
     const int se = tid >> 2, sub = tid & 3;
-    int par = 0;
-    for (uint32_t base = beg; base < end; base += B, par ^= 1) {
+    for (uint32_t base = beg; base < end; base += B) {
         const int cnt = (int)min((uint32_t)B, end - base);
-        S2D_T(t0);
         if (se < cnt) {
             // the forward pass of this iteration staged the same batch and left its lane masks behind
-            s_mask[sub * B + se] = wave_masks[(size_t)(base + se) * 4 + sub];
+            s.mask[sub * B + se] = wave_masks[(size_t)(base + se) * 4 + sub];
             if (sub == 0) {
                 const uint32_t idx = list[base + se];
                 const ProjRec* r = proj + idx;
@@ -487,21 +470,18 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                 const float4 q3 = r->q3; // sin, 1/sx^3, 1/sy^3, (sx^2-sy^2)/(sx^2 sy^2): divided once per splat (pack_proj)
                 const float cosT = q2.w, sinT = q3.x;
                 const float cc = cosT * cosT, ss = sinT * sinT, sc2 = 2.0f * sinT * cosT;
-                s_q0[se] = q0;
-                s_q1[se] = make_float4(q0.w, q1.x, q1.y, q1.z);
-                s_q2[se] = make_float4(q1.w, q2.x, q3.w, sinT * cosT);
-                s_e0[se] = make_float4(cc, ss, sc2, -sc2);
-                s_e1[se] = make_float4(ss, cc, q3.y, q3.z);
-                s_idx[par][se] = idx;
+                s.q0[se] = q0;
+                s.q1[se] = make_float4(q0.w, q1.x, q1.y, q1.z);
+                s.q2[se] = make_float4(q1.w, q2.x, q3.w, sinT * cosT);
+                s.e0[se] = make_float4(cc, ss, sc2, cc - ss);
+                s.e1[se] = make_float4(ss, cc, q3.y, q3.z);
             }
         }
-        S2D_T(t1);
         __syncthreads();
-        S2D_T(t2);
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
         unsigned long long touched = 0ull;
         if (alive_mask != 0ull || COUNT) {
-            const unsigned long long my_mask = (lane < cnt) ? s_mask[w * B + lane] : 0ull;
+            const unsigned long long my_mask = (lane < cnt) ? s.mask[w * B + lane] : 0ull;
             unsigned long long cand = __ballot(my_mask != 0ull);
             while (cand != 0ull) {
                 const int e = __builtin_ctzll(cand);
@@ -512,9 +492,6 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                 if (act_mask == 0ull) continue;
                 touched |= 1ull << e;
                 if (COUNT) n_exec += (lane == 0);
-#ifdef S2D_PHASE_TIMING
-                n_exec_t++;
-#endif
                 // Lanes this splat does not visit (main.cpp:595-598) or whose pixel is already below the throughput
                 // cut-off (main.cpp:604) run the same instructions with alpha forced to 0: then c += T*c*0 and
                 // T *= 1 are exact no-ops and every gradient term below is a multiple of alpha, i.e. exactly 0 --
@@ -526,8 +503,8 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                 }
                 float g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op = 0.f;
                 {
-                    const float4 q0 = s_q0[e], q1 = s_q1[e], q2 = s_q2[e];
-                    const float4 e0 = s_e0[e], e1 = s_e1[e];
+                    const float4 q0 = s.q0[e], q1 = s.q1[e], q2 = s.q2[e];
+                    const float4 e0 = s.e0[e], e1 = s.e1[e];
                     // ---- the reference's operations, in its order (decides T, alive, the running colour) ----
                     const f2 v = pxy - mk2(q0.x, q0.y);                              // main.cpp:607-608
                     const f2 m = mk2(q0.z, q0.w) * v.x + mk2(q1.x, q1.y) * v.y;      // inv_cov * v
@@ -566,32 +543,37 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
                     g_py = g_pos.y;
                     const f2 vv = v.x * v;                                           // vx*vx, vx*vy
                     const float vyy = v.y * v.y;
-                    // both covariance dot products at once: (cc,ss)*vxx + (2sc,-2sc)*vxy, then + (ss,cc)*vyy
-                    const f2 dots = (mk2(e0.x, e0.y) * vv.x + mk2(e0.z, e0.w) * vv.y) + mk2(e1.x, e1.y) * vyy;
+                    // both covariance dot products (main.cpp:657-662): (cc, ss)*vxx +- 2sc*vxy, then + (ss, cc)*vyy
+                    // (x + (-2sc)*vxy and x - 2sc*vxy are the same IEEE operation)
+                    const float sc2vxy = e0.z * vv.y;
+                    const f2 dots = mk2(e0.x * vv.x + sc2vxy, e0.y * vv.x - sc2vxy) + mk2(e1.x, e1.y) * vyy;
                     const f2 g_s = (ga * mk2(e1.z, e1.w)) * dots;                    // main.cpp:657-662, :677-678
                     g_sx = g_s.x;
                     g_sy = g_s.y;
-                    g_rot = (ga * q2.z) * ((e0.x - e0.y) * v.x * v.y - q2.w * (vv.x - vyy)); // main.cpp:680-685
+                    g_rot = (ga * q2.z) * (e0.w * v.x * v.y - q2.w * (vv.x - vyy)); // main.cpp:680-685, e0.w = cc - ss
                     if (NEED_OP) g_op = on ? gs * G : 0.0f;                           // main.cpp:703-704
                     T *= (1.0f - alpha);                                             // main.cpp:707
                     alive_mask &= __ballot(!(T < kMinThroughput));
                 }
                 // order of the record: pos.xy, sx, sy, rot, color.rgb, opacity (main.cpp:85-93)
-                const float tot = wave_sum8_lds<NEED_OP>(s_xpose[w], lane, g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
-                float* part = reinterpret_cast<float*>(&s_part[DET ? w : 0][e][0]);
+                const float tot = wave_sum8_lds<NEED_OP>(s.xpose[w], lane, g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op);
+                // slot of (wave, entry, component), 12 dwords per entry.  The entry's share of the index is computed on the
+                // scalar unit explicitly: left to itself the compiler folds e * 12 + lane term into a per-lane
+                // v_mad_u64_u32 in the blend loop.
+                float* const part = reinterpret_cast<float*>(&s.part[0][0][0]);
+                int pe;
+                asm("s_mul_i32 %0, %1, 12" : "=s"(pe) : "s"((DET ? __builtin_amdgcn_readfirstlane(w) : 0) * B + e));
                 if (DET) {
-                    if ((lane & 7) == 0) part[part_slot] = tot;
-                    if (NEED_OP && lane == 63) part[8] = g_op;
+                    if ((lane & 7) == 0) part[pe + part_slot] = tot;
+                    if (NEED_OP && lane == 63) part[pe + 8] = g_op;
                 } else {
-                    if ((lane & 7) == 0) __hip_atomic_fetch_add(part + part_slot, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (NEED_OP && lane == 63) __hip_atomic_fetch_add(part + 8, g_op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((lane & 7) == 0) __hip_atomic_fetch_add(part + (pe + part_slot), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (NEED_OP && lane == 63) __hip_atomic_fetch_add(part + (pe + 8), g_op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
-        if (DET && lane == 0) s_touched[w] = touched;
-        S2D_T(t3);
+        if (DET && lane == 0) s.touched[w] = touched;
         const int any = __syncthreads_or(alive_mask != 0ull ? 1 : 0);
-        S2D_T(t4);
         // one burst per (tile, splat): 9 consecutive floats -- float atomics into grads[idx], or (deterministic
         // mode) plain stores into this tile's own slot of the splat, summed later in a fixed order
         for (int i = tid; i < cnt * 9; i += 256) {
@@ -601,52 +583,107 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
             bool any_w = false;
             if (DET) {
 #pragma unroll
-                for (int ww = 0; ww < kPartWaves; ww++)
-                    if ((s_touched[ww] >> e) & 1ull) {
-                        v += reinterpret_cast<const float*>(&s_part[ww][e][0])[k];
+                for (int ww = 0; ww < (DET ? 4 : 1); ww++)
+                    if ((s.touched[ww] >> e) & 1ull) {
+                        v += reinterpret_cast<const float*>(&s.part[ww][e][0])[k];
                         any_w = true;
                     }
             } else {
-                float* slot = reinterpret_cast<float*>(&s_part[0][e][0]) + k;
+                float* slot = reinterpret_cast<float*>(&s.part[0][e][0]) + k;
                 v = *slot;
                 *slot = 0.0f; // the next batch's waves add after the staging barrier
                 any_w = true;
             }
             if (DET) {
                 if (any_w) {
-                    const uint32_t idx = s_idx[par][e];
+                    const uint32_t idx = list[base + e];
                     const TileRect r = det.rects[idx];
-                    const uint32_t slot = det.offsets[idx] + (uint32_t)(ty - g.trow0 - r.ty0) * (uint32_t)(r.tx1 - r.tx0 + 1) +
-                                          (uint32_t)(tx - r.tx0);
+                    const uint32_t slot = det.offsets[idx] + (uint32_t)(c.ty - g.trow0 - r.ty0) * (uint32_t)(r.tx1 - r.tx0 + 1) +
+                                          (uint32_t)(c.tx - r.tx0);
                     det.data[(size_t)slot * 9 + k] = (!NEED_OP && k == 8) ? 0.0f : v;
                     if (k == 0) det.stamp[slot] = det.now;
                 }
             } else if (any_w && v != 0.0f) {
-                atomicAdd(grads + (size_t)s_idx[par][e] * 9 + k, v);
+                atomicAdd(grads + (size_t)list[base + e] * 9 + k, v); // the index again from the list (an L2 hit)
             }
         }
-        S2D_T(t5);
-        S2D_TACC(0, t0, t1);
-        S2D_TACC(1, t1, t2);
-        S2D_TACC(2, t2, t3);
-        S2D_TACC(3, t3, t4);
-        S2D_TACC(4, t4, t5);
         if (!any) break;
     }
-#ifdef S2D_PHASE_TIMING
-    if (lane == 0) {
-        S2D_T(tk1);
-        for (int k = 0; k < 5; k++) atomicAdd(&counters->phase_cycles[8 + k], ph[k]);
-        atomicAdd(&counters->phase_cycles[14], (unsigned long long)(tk1 - tk0));
-        atomicAdd(&counters->phase_cycles[15], n_exec_t);
-    }
-#endif
     if (COUNT) {
         atomicAdd(&counters->bwd_visited, n_vis);
         atomicAdd(&counters->bwd_active, n_act);
         if (tid == 0) atomicAdd(&counters->bwd_staged, n_staged);
         if (lane == 0) atomicAdd(&counters->bwd_wave_execs, n_exec);
     }
+}
+
+template <bool COUNT, bool NEED_OP, bool HALF, bool DET, bool EXACT>
+__global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __restrict__ tile_off,
+                                                              const uint32_t* __restrict__ list,
+                                                              const ProjRec* __restrict__ proj,
+                                                              const void* __restrict__ image0,
+                                                              const void* __restrict__ image_ref,
+                                                              const unsigned long long* __restrict__ wave_masks,
+                                                              float* __restrict__ grads,
+                                                              double* __restrict__ tile_sqerr, Geometry g,
+                                                              DetSlots det, const DeviceStatus* __restrict__ status,
+                                                              int iteration, PairCounters* __restrict__ counters)
+{
+    __shared__ BwdShared<DET> s;
+    if (launch_is_void(status, 0, iteration)) return; // the reference abort()ed in an earlier iteration
+    const int tile = tile_of_block(blockIdx.x, g);
+    if (tile < 0) return;
+    const TileCtx c = tile_ctx(tile, g);
+    float4 fin = make_float4(0.f, 0.f, 0.f, 0.f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c.inside) {
+        fin = load_pixel<HALF>(image0, (size_t)c.y * g.W + c.x);    // finalColor, main.cpp:613
+        ref = load_pixel<HALF>(image_ref, (size_t)c.y * g.W + c.x);
+    }
+    backward_tile<COUNT, NEED_OP, DET, EXACT>(s, c, fin, ref, tile_off, list, proj, wave_masks, grads, tile_sqerr, g, det, counters);
+}
+
+// Forward and backward walk of a tile in ONE launch (what s2d_step and s2d_forward_backward queue): a tile's backward
+// pass needs nothing but its own pixels' final colours, which are still in registers when the forward walk ends.  One
+// dispatch, one ramp-down tail and one read of image0 (16 B per pixel) less per iteration than the two kernels above,
+// which remain for callers that run the passes separately.  The lane masks still travel through wave_masks (written
+// and read back by the same workgroup, so they rarely leave L2).  With S2D_CFG_FP16_IMAGES the backward walk sees the
+// final colour as stored, i.e. rounded to fp16, exactly like the separate kernels.  image0 is written only when
+// `write_image` is set (s2d_step: the last iteration of the call; nothing else reads it).
+template <bool NEED_OP, bool HALF, bool DET, bool EXACT>
+__global__ __launch_bounds__(256) void raster_fused_kernel(const uint32_t* __restrict__ tile_off,
+                                                           const uint32_t* __restrict__ list,
+                                                           const ProjRec* __restrict__ proj, void* __restrict__ image0,
+                                                           const void* __restrict__ image_ref,
+                                                           unsigned long long* __restrict__ wave_masks,
+                                                           float* __restrict__ grads, double* __restrict__ tile_sqerr,
+                                                           Geometry g, DetSlots det,
+                                                           const DeviceStatus* __restrict__ status, int abort_stamp,
+                                                           int iteration, int write_image)
+{
+    constexpr size_t kBytes = sizeof(BwdShared<DET>) > sizeof(FwdShared) ? sizeof(BwdShared<DET>) : sizeof(FwdShared);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kBytes]; // the two walks use the same LDS one after the other
+    if (launch_is_void(status, abort_stamp, iteration)) return;
+    const int tile = tile_of_block(blockIdx.x, g);
+    if (tile < 0) return;
+    const TileCtx c = tile_ctx(tile, g);
+    f2 crg;
+    float cb;
+    forward_tile<false, EXACT>(*reinterpret_cast<FwdShared*>(smem), c, tile_off, list, proj, wave_masks, g, nullptr, crg, cb);
+    float4 fin = make_float4(crg.x, crg.y, cb, 1.0f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (HALF) { // what the backward pass would read back from the fp16 framebuffer
+        const __half2 a = __floats2half2_rn(fin.x, fin.y), b = __floats2half2_rn(fin.z, fin.w);
+        const float2 fa = __half22float2(a), fb = __half22float2(b);
+        fin = make_float4(fa.x, fa.y, fb.x, fb.y);
+    }
+    if (c.inside) {
+        if (write_image) store_pixel<HALF>(image0, (size_t)c.y * g.W + c.x, fin); // .w reset, main.cpp:543-546
+        ref = load_pixel<HALF>(image_ref, (size_t)c.y * g.W + c.x);
+    } else {
+        fin = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // (the forward walk ended with a workgroup barrier behind its last LDS read, or never touched LDS)
+    backward_tile<false, NEED_OP, DET, EXACT>(*reinterpret_cast<BwdShared<DET>*>(smem), c, fin, ref, tile_off, list, proj,
+                                              wave_masks, grads, tile_sqerr, g, det, nullptr);
 }
 
 // Deterministic mode: gradient of splat i = sum of the partials its tiles stored this iteration, in emission
@@ -673,54 +710,15 @@ __global__ __launch_bounds__(256) void gather_grads_kernel(const uint32_t* __res
 }
 
 // Sum of the per-tile squared errors in a fixed order (deterministic MSE trace), two stages in one launch:
-// kSqerrBlocks blocks each reduce a contiguous chunk to partial[b]; the block that finishes last (ticket counter)
-// adds the partials, again in a fixed order, and re-arms the counter.  scratch = kSqerrBlocks doubles + one
+// kSqerrChunks blocks each reduce a contiguous chunk to partial[b] (sqerr_reduce, s2d_device.h); the block that finishes last (ticket counter)
+// adds the partials, again in a fixed order, and re-arms the counter.  scratch = kSqerrChunks doubles + one
 // 64-bit counter, zero before the first launch (s2d_api.hip allocates it behind tile_sqerr).
-constexpr int kSqerrBlocks = 64;
-
-__device__ __forceinline__ double block_sum_256(double v, double* s)
-{
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return ((s[0] + s[1]) + s[2]) + s[3];
-}
-
 __global__ __launch_bounds__(256) void sqerr_finalize_kernel(const double* __restrict__ tile_sqerr, int num_tiles,
                                                              double* __restrict__ out, double* scratch,
                                                              const DeviceStatus* __restrict__ status, int iteration)
 {
-    __shared__ double s[4];
-    __shared__ bool last;
     if (status->first_nonfinite_iter < iteration) return;
-    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(scratch + kSqerrBlocks);
-    const int chunk = (num_tiles + kSqerrBlocks - 1) / kSqerrBlocks;
-    const int beg = blockIdx.x * chunk, end = min(beg + chunk, num_tiles);
-    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
-    for (int i = beg + (int)threadIdx.x; i < end; i += 1024) {
-        a0 += tile_sqerr[i];
-        if (i + 256 < end) a1 += tile_sqerr[i + 256];
-        if (i + 512 < end) a2 += tile_sqerr[i + 512];
-        if (i + 768 < end) a3 += tile_sqerr[i + 768];
-    }
-    const double part = block_sum_256((a0 + a1) + (a2 + a3), s);
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(scratch + blockIdx.x, part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();
-        last = atomicAdd(ticket, 1ull) == (unsigned long long)(kSqerrBlocks - 1);
-    }
-    __syncthreads();
-    if (!last) return;
-    __threadfence();
-    const double p = threadIdx.x < kSqerrBlocks
-                         ? __hip_atomic_load(scratch + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                         : 0.0;
-    const double total = block_sum_256(p, s);
-    if (threadIdx.x == 0) {
-        *out = total;
-        *ticket = 0ull;
-    }
+    sqerr_reduce(tile_sqerr, num_tiles, out, scratch, (int)blockIdx.x, kSqerrChunks);
 }
 
 static inline unsigned raster_grid(int num_tiles) { return (unsigned)(((num_tiles + 7) / 8) * 8); }
@@ -782,10 +780,40 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
     return hipGetLastError();
 }
 
+hipError_t launch_raster_fused(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
+                               const void* image_ref, bool half_images, unsigned long long* wave_masks, float* grads,
+                               double* tile_sqerr, Geometry g, bool need_opacity_grad, const DetGather* dg,
+                               const DeviceStatus* status, int abort_stamp, int iteration, bool write_image, bool exact_exp,
+                               hipStream_t stream)
+{
+    if (g.num_tiles <= 0) return hipSuccess;
+    DetSlots det{nullptr, nullptr, nullptr, nullptr, 0u};
+    if (dg) det = DetSlots{dg->rects, dg->offsets, dg->data, dg->stamp, dg->now};
+    const dim3 grid(raster_grid(g.num_tiles)), block(256);
+    const int wi = write_image ? 1 : 0;
+#define S2D_LAUNCH_FUSED(O, H, D, X)                                                                                       \
+    hipLaunchKernelGGL((raster_fused_kernel<O, H, D, X>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
+                       wave_masks, grads, tile_sqerr, g, det, status, abort_stamp, iteration, wi)
+#define S2D_LAUNCH_FUSED_D(O, H, X) do { if (dg) S2D_LAUNCH_FUSED(O, H, true, X); else S2D_LAUNCH_FUSED(O, H, false, X); } while (0)
+    if (exact_exp) {
+        if (need_opacity_grad) S2D_LAUNCH_FUSED_D(true, false, true); else S2D_LAUNCH_FUSED_D(false, false, true);
+    } else if (half_images) {
+        if (need_opacity_grad) S2D_LAUNCH_FUSED_D(true, true, false); else S2D_LAUNCH_FUSED_D(false, true, false);
+    } else {
+        if (need_opacity_grad) S2D_LAUNCH_FUSED_D(true, false, false); else S2D_LAUNCH_FUSED_D(false, false, false);
+    }
+#undef S2D_LAUNCH_FUSED_D
+#undef S2D_LAUNCH_FUSED
+    if (dg && dg->n > 0)
+        hipLaunchKernelGGL(gather_grads_kernel, dim3((dg->n + 255) / 256), dim3(256), 0, stream, dg->offsets, dg->counts,
+                           dg->n, dg->data, dg->stamp, dg->now, grads);
+    return hipGetLastError();
+}
+
 hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double* out, double* scratch,
                                  const DeviceStatus* status, int iteration, hipStream_t stream)
 {
-    hipLaunchKernelGGL(sqerr_finalize_kernel, dim3(kSqerrBlocks), dim3(256), 0, stream, tile_sqerr, num_tiles, out, scratch,
+    hipLaunchKernelGGL(sqerr_finalize_kernel, dim3(kSqerrChunks), dim3(256), 0, stream, tile_sqerr, num_tiles, out, scratch,
                        status, iteration);
     return hipGetLastError();
 }

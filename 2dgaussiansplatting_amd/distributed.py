@@ -1,20 +1,32 @@
 """Row-slab data parallelism: one process per GPU, gradient rows are the only per-iteration exchange.
 
-Two exchange schemes over the same slab partition:
-  * SlabStep  -- splats and Adam state replicated, dense all-reduce of the N x 9 gradients (36 MB at N = 10^6);
-  * HaloStep  -- slab OWNERSHIP: a rank holds, lists and updates only the splats that can reach its rows (plus a
-                 halo margin) and exchanges gradient rows only for splats held by more than one rank (DESIGN.md
-                 section 7).  bench.py uses this one for N > 1.
+Partition: the image is cut into `world` contiguous slabs of whole 16-pixel tile rows; per iteration
+every rank rasterises its slab forward and backward (partial gradients, partial squared error).  Framebuffers and
+parameters are never exchanged.  Two exchange schemes sit on that partition:
+  * HaloStep  -- slab OWNERSHIP (bench.py's default for N > 1): a rank holds, lists and updates only the splats that
+                 can reach its rows (plus a halo margin) and exchanges gradient rows only for splats held by more than
+                 one rank -- one all_to_all per iteration;
+  * SlabStep  -- splats and Adam state replicated on every rank, the N x 9 fp32 gradient array all-reduced (sum; 36 MB
+                 at N = 10^6) -- RCCL over xGMI on GPUs, gloo in the CPU tests -- and every rank applies the identical
+                 Adam step, so the replicas stay bit-identical (bench.py --exchange dense: north_star's scheme).
 
-Partition: the image is cut into `world` contiguous slabs of whole 16-pixel tile rows; splats
-and Adam state are replicated.  Per iteration every rank rasterises its slab forward and backward (partial
-gradients, partial squared error), the N x 9 fp32 gradient array is all-reduced (sum) -- RCCL over xGMI on
-GPUs, gloo in the CPU tests -- and every rank applies the identical Adam step, so the replicas stay bit-identical
-without ever exchanging parameters or framebuffers.
-
-`backend` is anything with forward() / backward() / adam_step(): the HIP Trainer bound to a torch gradient
-tensor in bench.py, or the oracle-backed stand-in of tests/test_distributed_cpu.py.
+`backend` is anything with forward() / backward() / adam_step() (and optionally forward_backward(), the fused form):
+the HIP Trainer in bench.py, or the oracle-backed stand-in of tests/test_distributed_cpu.py.
 """
+
+
+def _raster(backend, before, after):
+    """Forward + backward of one iteration: the fused launch where the backend has one."""
+    if before is not None:
+        before()
+    fused = getattr(backend, "forward_backward", None)
+    if fused is not None:
+        fused()
+    else:
+        backend.forward()
+        backend.backward()
+    if after is not None:
+        after()
 
 
 def slab_rows(height, rank, world, tile=16):
@@ -34,13 +46,8 @@ class SlabStep:
         self.grads = grads  # torch tensor aliasing the backend's gradient buffer (n * 9 fp32)
         self.dist = dist    # torch.distributed module, or None for a single process
 
-    def __call__(self, after_forward=None, after_backward=None):
-        self.backend.forward()
-        if after_forward is not None:
-            after_forward()
-        self.backend.backward()
-        if after_backward is not None:
-            after_backward()
+    def __call__(self, before_raster=None, after_raster=None):
+        _raster(self.backend, before_raster, after_raster)
         if self.dist is not None:
             self.dist.all_reduce(self.grads)  # sum of the slabs' partial gradients, in place
         self.backend.adam_step()
@@ -327,13 +334,8 @@ class HaloStep:
         ops.halo_commit(self.mask, r, added=got.shape[0] > 0)  # departures alone leave the tile lists valid
         self._plan()
 
-    def __call__(self, after_forward=None, after_backward=None):
-        self.backend.forward()
-        if after_forward is not None:
-            after_forward()
-        self.backend.backward()
-        if after_backward is not None:
-            after_backward()
+    def __call__(self, before_raster=None, after_raster=None):
+        _raster(self.backend, before_raster, after_raster)
         if self.world > 1:
             self._exchange_grads()
         self.backend.adam_step()

@@ -215,8 +215,8 @@ def main():
     def one_step(ev=None):
         if ev is None:
             step()
-        else:  # HIP events around the backward raster kernel, on the stream it is launched on
-            step(after_forward=lambda: ev[0].record(stream), after_backward=lambda: ev[1].record(stream))
+        else:  # HIP events around the raster kernel (fused forward + backward), on the stream it is launched on
+            step(before_raster=lambda: ev[0].record(stream), after_raster=lambda: ev[1].record(stream))
 
     for _ in range(args.warmup):
         one_step()
@@ -264,10 +264,12 @@ def main():
 
     if rank == 0:
         its = args.steps / dt
-        # dominant kernel: raster_backward.  Algorithmic bytes per launch: per
-        # pixel of the slab it reads the framebuffer (16 B) and the target (16 B); per splat it reads the
-        # parameters once (36 B) and writes the 9 gradient floats once (36 B).
-        bwd_bytes = 32.0 * W * (r1 - r0) + 72.0 * n
+        # dominant kernel: raster_fused_kernel = forward + backward walk of every tile.  Algorithmic bytes per launch
+        # (SURVEY.md section 8d's per-unit figures): per pixel of the slab the forward part writes
+        # the framebuffer (16 B), the backward part reads it (16 B) and the target (16 B); per splat the parameters are
+        # read once per pass (2 x 36 B) and the 9 gradient floats written once (36 B).  (The events also span the
+        # ~6 us squared-error reduction queued behind it.)
+        bwd_bytes = 48.0 * W * (r1 - r0) + 108.0 * n
         bwd_s = float(bwd_ms.item()) * 1e-3
         achieved = bwd_bytes / bwd_s / 1e9 if bwd_s > 0 else 0.0
         # HBM traffic of that kernel from the PMC counters: a RECORDED figure (rocprofv3 cannot run inside this
@@ -329,7 +331,7 @@ def main():
                                if isinstance(step, D.HaloStep) else {"scheme": "dense" if world > 1 else "none"}),
             "pairs_binned_rank0": stats["pairs_binned"],
             "rebins_rank0": stats["rebins"],
-            "roofline": {"bound": "hbm", "kernel": "raster_backward_kernel", "achieved": achieved, "peak": 8000.0,
+            "roofline": {"bound": "hbm", "kernel": "raster_fused_kernel", "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel_ms": float(bwd_ms.item()), "algorithmic_bytes_per_launch": bwd_bytes},
         }
@@ -343,16 +345,14 @@ def main():
                 tc.set_target_synthetic()
                 tc.set_splats(sp)
                 tc.forward()
-                tc.backward()
+                tc.backward()   # a counting context runs the two separate kernels (same walks as the fused one)
                 tc.synchronize()
                 cs = tc.stats()
             flops = 30.0 * cs["fwd_active"] + 110.0 * cs["bwd_active"]
             out["compute"] = {"unit": "TFLOP/s", "achieved": flops * its / 1e12, "peak": 157.3,
                               "frac": flops * its / 1e12 / 157.3, "active_pairs_per_pass": cs["bwd_active"],
                               "lanes_per_executed_wave_entry": cs["bwd_active"] / max(cs["bwd_wave_execs"], 1),
-                              # backward kernel against the measured gfx950 instruction costs (DESIGN.md section 4,
-                              # profiles/r01/valu_rates.txt): ~290 SIMD cycles per executed (wave, entry), 1024 SIMDs
-                              "bwd_simd_busy_model": (cs["bwd_wave_execs"] * 290.0) / (1024 * 2.4e9 * bwd_s) if bwd_s > 0 else None,
+                              "executed_wave_entries_per_pass": cs["bwd_wave_execs"],
                               "note": "useful fp32 VALU flops only; kernels are VALU-issue-bound (DESIGN.md section 4)"}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or host_cores()

@@ -134,8 +134,6 @@ typedef struct s2d_stats {
     int32_t first_nonfinite_iteration; /* -1 if none */
     uint64_t fwd_staged_hit;   /* S2D_CFG_COUNT_PAIRS: staged entries that cover >= 1 pixel of their tile ... */
     uint64_t fwd_rows_hit;     /* ... and (staged entry, tile row) pairs with a non-empty column range (of 16 per entry) */
-    uint64_t phase_cycles[16]; /* zero except in -DS2D_PHASE_TIMING diagnostic builds (tools/build_timing_lib.py):
-                                * shader-clock cycles the raster kernels' waves spent per phase */
 } s2d_stats;
 
 typedef struct s2d_ctx s2d_ctx;
@@ -168,6 +166,10 @@ int s2d_get_image(s2d_ctx* ctx, float* rgba32f);
 /* Backward pass, main.cpp:548-712: accumulates this slab's contribution into the gradient buffer
  * (which s2d_adam_step / s2d_step re-zero after use, like main.cpp:550).  Needs s2d_forward first. */
 int s2d_backward(s2d_ctx* ctx, uint32_t flags);
+/* s2d_forward + s2d_backward in one kernel launch per tile (same results: a tile's backward walk needs only its own
+ * pixels' final colours).  What s2d_step queues; for callers that put their own work between backward and Adam (the
+ * multi-GPU exchange).  flags as s2d_backward. */
+int s2d_forward_backward(s2d_ctx* ctx, uint32_t flags);
 int s2d_get_grads(s2d_ctx* ctx, s2d_splat* dsplats);
 
 /* Adam + constraints + finite guard, main.cpp:714-785, on the current gradient buffer; then iterations++ (809). */

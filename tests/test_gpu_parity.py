@@ -1002,3 +1002,50 @@ def test_adam_fp32_quotient_mode_matches_the_oracle_in_that_mode():
         O.lib().s2do_set_adam_fp32(0)
     err = O.step_delta_error(before, got, o.splats.view(np.float32).reshape(-1, 9))
     assert err.max() <= STEP_REL, err.max()
+
+
+@pytest.mark.parametrize("kw", [{}, {"deterministic": True}, {"fp16_images": True}, {"deterministic": True, "fp16_images": True}])
+def test_fused_forward_backward_equals_the_two_passes(kw):
+    """s2d_forward_backward (one launch per tile, what s2d_step queues) against s2d_forward + s2d_backward: identical
+    framebuffer, identical squared error, and gradients that are bitwise equal with deterministic sums (same terms,
+    same order) and equal to summation noise with float atomics."""
+    tgt = mini_target()
+    res = []
+    for fused in (False, True):
+        o, t = make_pair(tgt, 2000, 3, **kw)
+        if fused:
+            t.forward_backward()
+        else:
+            t.forward()
+            t.backward()
+        res.append((t.get_image(), t.get_grads().view(np.float32).reshape(-1, 9).copy(), t.mse()))
+        t.close()
+    (img_a, g_a, m_a), (img_b, g_b, m_b) = res
+    assert img_a.tobytes() == img_b.tobytes()
+    assert m_a == m_b
+    if kw.get("deterministic"):
+        assert g_a.tobytes() == g_b.tobytes()
+    else:
+        o.image0[:] = 0
+        if kw.get("fp16_images"):
+            pass  # bars against the oracle are checked by test_fp16_images_*; here only fused vs separate
+        scale = np.abs(g_a).max(axis=0) + 1e-30
+        assert (np.abs(g_a - g_b) / scale).max() <= 1e-5
+
+
+def test_step_leaves_the_image_of_its_last_iteration():
+    """s2d_step stores image0 only in the last iteration of the call (nothing can observe the others): what
+    s2d_get_image returns afterwards is the framebuffer rendered from the parameters BEFORE the last update, as
+    uploaded at main.cpp:794."""
+    tgt = mini_target()
+    with S2D.Trainer(268, 213, 1500, deterministic=True) as a, S2D.Trainer(268, 213, 1500, deterministic=True) as b:
+        for t in (a, b):
+            t.set_target(tgt)
+            t.init()
+        a.step(4)
+        b.step(3)
+        b.forward()
+        assert a.get_image().tobytes() == b.get_image().tobytes()
+        b.backward()
+        b.adam_step()
+        assert a.get_splats().tobytes() == b.get_splats().tobytes()   # and the separate passes train identically
