@@ -64,7 +64,7 @@ ABI_SYMBOLS = [
     "s2d_abi_version", "s2d_create", "s2d_destroy", "s2d_set_target", "s2d_set_target_synthetic",
     "s2d_init_splats", "s2d_set_splats", "s2d_get_splats", "s2d_set_adam", "s2d_get_adam", "s2d_forward",
     "s2d_get_image", "s2d_backward", "s2d_forward_backward", "s2d_get_grads", "s2d_adam_step", "s2d_step", "s2d_get_mse",
-    "s2d_bind_grads_device", "s2d_grads_device_ptr", "s2d_get_sqerr_trace", "s2d_synchronize", "s2d_get_stats",
+    "s2d_bind_grads_device", "s2d_grads_device_ptr", "s2d_stream", "s2d_get_sqerr_trace", "s2d_synchronize", "s2d_get_stats",
     "s2d_get_rebuild_count",
     "s2d_last_error", "s2d_test_sincos", "s2d_test_sort_pairs", "s2d_test_exclusive_scan",
     "s2d_debug_get_tile_lists",
@@ -118,6 +118,7 @@ def load_library(path=None):
     sig("s2d_get_mse", [vp, vp])
     sig("s2d_bind_grads_device", [vp, vp])
     sig("s2d_grads_device_ptr", [vp], restype=vp)
+    sig("s2d_stream", [vp], restype=vp)
     sig("s2d_get_sqerr_trace", [vp, i32, i32, vp])
     sig("s2d_synchronize", [vp])
     sig("s2d_get_stats", [vp, C.POINTER(_Stats)])

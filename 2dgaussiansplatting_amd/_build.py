@@ -59,8 +59,12 @@ def build_host_program(force=False, verbose=False):
     deps = [src, os.path.join(HOST_DIR, "image_io.h"), os.path.join(HOST_DIR, "overlay.h"), os.path.join(HOST_DIR, "jpeg_decode.h"),
             os.path.join(ROOT, "include", "splat2d.h"), LIB_PATH]
     if force or _stale(TRAIN_BIN, deps):
-        cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", TRAIN_BIN, src,
-               "-L", LIB_DIR, "-lsplat2d_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+        # rccl.h pulls in the HIP runtime API header: plain C declarations, fine for g++ (no device code in the host)
+        cmd = ["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+               "-I", os.path.join(rocm, "include"), "-o", TRAIN_BIN, src,
+               "-L", LIB_DIR, "-lsplat2d_hip", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lz", "-lpthread",
+               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -695,6 +695,8 @@ int s2d_bind_grads_device(s2d_ctx* c, void* grads_device)
 
 void* s2d_grads_device_ptr(s2d_ctx* c) { return c ? (void*)c->d_grads : nullptr; }
 
+void* s2d_stream(s2d_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
 // ---- slab ownership (s2d_halo.hip): all pointers below are device pointers of the caller ----
 
 int s2d_halo_masks(s2d_ctx* c, int32_t world, const int32_t* row_bounds, float margin_rows, uint32_t* masks_device)

@@ -217,6 +217,9 @@ int s2d_grads_combine(s2d_ctx* ctx, const int32_t* rows_device, int32_t n_rows, 
 int s2d_bind_grads_device(s2d_ctx* ctx, void* grads_device);
 /* Device address of the gradient buffer currently in use. */
 void* s2d_grads_device_ptr(s2d_ctx* ctx);
+/* The hipStream_t the context queues its work on (s2d_config.stream, or the one it created): a caller that puts its
+ * own device work between two calls -- the RCCL all-reduce of host/splat2d_train.cpp --gpus N -- queues it here. */
+void* s2d_stream(s2d_ctx* ctx);
 /* Per-iteration sums of squared errors of this slab kept on the device (ring of `capacity` doubles indexed by
  * iteration % capacity); lets a multi-GPU host reduce them once after many steps instead of every iteration. */
 int s2d_get_sqerr_trace(s2d_ctx* ctx, int32_t first_iteration, int32_t count, double* out);

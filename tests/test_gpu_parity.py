@@ -1049,3 +1049,24 @@ def test_step_leaves_the_image_of_its_last_iteration():
         b.backward()
         b.adam_step()
         assert a.get_splats().tobytes() == b.get_splats().tobytes()   # and the separate passes train identically
+
+
+def test_cpp_host_multi_gpu_path_through_rccl_on_one_gpu():
+    """host/splat2d_train.cpp --gpus N: one thread + one context per GPU, ncclAllReduce of the N x 9 gradients between
+    s2d_forward_backward and s2d_adam_step.  This box has one GPU (RCCL takes one rank per GPU), so the test sends
+    --gpus 1 through that same code (S2D_TRAIN_FORCE_RCCL): communicator set-up, the in-place all-reduce on the
+    context's stream, the host-side sum of the slabs' squared errors and the reference's trace line."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(S2D.__file__), "lib", "splat2d_train")
+    args = [exe, "--image", MINI, "--splats", "1024", "--iters", "12", "--batch", "4"]
+    want = subprocess.run(args, capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    env = dict(os.environ, S2D_TRAIN_FORCE_RCCL="1")
+    p = subprocess.run(args + ["--gpus", "1"], capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = [ln for ln in p.stdout.strip().splitlines() if " itr, mse " in ln]
+    assert got[0] == "0 itr, mse 5934.9042" and len(got) == 12
+    np.testing.assert_allclose([float(l.split("mse")[1]) for l in got], [float(l.split("mse")[1]) for l in want], rtol=2e-5)
+    assert "RCCL all-reduce" in p.stderr
+    # more ranks than this box has GPUs: a clean error, not a crash
+    p = subprocess.run(args + ["--gpus", "2"], capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and p.stdout.strip() == ""
