@@ -56,7 +56,7 @@ class _Stats(C.Structure):
                 ("bwd_active", C.c_uint64), ("fwd_staged", C.c_uint64), ("bwd_staged", C.c_uint64),
                 ("fwd_wave_execs", C.c_uint64), ("bwd_wave_execs", C.c_uint64), ("bwd_lane_hist", C.c_uint64 * 65),
                 ("iterations", C.c_int32), ("first_nonfinite_iteration", C.c_int32),
-                ("fwd_staged_hit", C.c_uint64), ("fwd_rows_hit", C.c_uint64)]
+                ("fwd_staged_hit", C.c_uint64), ("fwd_rows_hit", C.c_uint64), ("bwd_quadrant_execs", C.c_uint64)]
 
 
 # every symbol include/splat2d.h declares

@@ -689,6 +689,7 @@ int s2d_get_mse(s2d_ctx* c, double* mse)
 int s2d_bind_grads_device(s2d_ctx* c, void* grads_device)
 {
     if (!c) return S2D_E_INVALID;
+    if ((uintptr_t)grads_device & 15u) return fail(c, S2D_E_INVALID, "the gradient buffer must be 16-byte aligned");
     c->d_grads = grads_device ? (float*)grads_device : c->d_grads_own;
     return S2D_OK;
 }
@@ -820,6 +821,7 @@ int s2d_get_stats(s2d_ctx* c, s2d_stats* out)
     for (int k = 0; k < 65; k++) out->bwd_lane_hist[k] = pc.bwd_lane_hist[k];
     out->fwd_staged_hit = pc.fwd_staged_hit;
     out->fwd_rows_hit = pc.fwd_rows_hit;
+    out->bwd_quadrant_execs = pc.bwd_quadrant_execs;
     out->iterations = c->iterations;
     out->first_nonfinite_iteration = c->h_status->nonfinite ? c->h_status->first_nonfinite_iter : -1;
     return S2D_OK;

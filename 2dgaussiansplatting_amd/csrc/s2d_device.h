@@ -41,6 +41,7 @@ struct PairCounters {
     unsigned long long bwd_lane_hist[65]; // executed (wave, entry) pairs by number of active lanes
     unsigned long long fwd_staged_hit;    // staged entries with at least one pixel of the tile inside their ranges
     unsigned long long fwd_rows_hit;      // (staged entry, tile row) pairs with a non-empty column range
+    unsigned long long bwd_quadrant_execs; // executed (wave, entry) pairs weighted by their live 4x4 quadrants (1..4)
 };
 
 // Device-resident status word(s), written by kernels, read by the host at synchronisation points.

@@ -22,52 +22,18 @@ __global__ __launch_bounds__(256) void init_splats_kernel(float* __restrict__ sp
 
 __device__ __forceinline__ bool finite_f32(float x) { return (f32_bits(x) & 0x7f800000u) != 0x7f800000u; }
 
-// main.cpp:721-785 for one splat per thread.  The scalar order of Splat (pos.xy, sx, sy, rot, color.rgb,
-// opacity) and of SplatAdam (pos[2], sx, sy, rot, color[3], opacity) is the same, so scalar k of the splat
-// pairs with Adam slot k.  The nine updates are independent, so the reference's update order (color, pos,
-// sx, sy, rot, opacity; main.cpp:723-738) does not matter.  Also re-zeroes the gradient record
-// (main.cpp:550 value-initialises dSplats every iteration).
-// With proj != nullptr the thread goes on to project the updated splat (main.cpp:423-436, 489-491 of the NEXT
-// iteration's forward) and to check it against the rectangle its tile lists were built from, so that the next
-// iteration needs no separate projection pass over the parameters.
-__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, float* __restrict__ adams,
-                                                   float* __restrict__ grads, const uint32_t* __restrict__ held_ids,
-                                                   const uint32_t* __restrict__ held_count, int n, Geometry g,
-                                                   float beta1t,
-                                                   float beta2t, float lr, int optimize_opacity, int iteration,
-                                                   DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
-                                                   const TileRect* __restrict__ rects, int check_stamp,
-                                                   int* __restrict__ host_stamp, SqerrJob sq)
+// main.cpp:721-785 for one splat: the nine Adam updates, the constraints and the finite guard, on values held in
+// registers.  The scalar order of Splat (pos.xy, sx, sy, rot, color.rgb, opacity) and of SplatAdam (pos[2], sx, sy, rot,
+// color[3], opacity) is the same, so scalar k of the splat pairs with Adam slot k.  The nine updates are independent,
+// so the reference's update order (color, pos, sx, sy, rot, opacity; main.cpp:723-738) does not matter.
+// mode: bit 0 = optimizeOpacity (main.cpp:735-738), bit 1 = fp32 Adam quotient (S2D_CFG_ADAM_FP32).
+__device__ __forceinline__ void adam_update_one(float (&v)[9], float (&mv)[18], const float (&gr)[9], int W, int H, float beta1t,
+                                                float beta2t, float lr, int mode, int iteration, DeviceStatus* status)
 {
-    const int W = g.W, H = g.H;
-    // The reference abort()s at the first non-finite parameter (main.cpp:752-785): later iterations do nothing.
-    // (Strictly earlier: blocks of the detecting launch itself, which stores `iteration`, must all finish their work.)
-    if (status->first_nonfinite_iter < iteration) return;
-    // MSE of the iteration (main.cpp:796-805) from the tile errors the backward pass left, by this launch's first
-    // workgroups (block-uniform branch: all 256 threads take it together)
-    if (sq.tile_sqerr != nullptr && blockIdx.x < (unsigned)kSqerrChunks)
-        sqerr_reduce(sq.tile_sqerr, sq.num_tiles, sq.out, sq.scratch, (int)blockIdx.x, min((int)gridDim.x, kSqerrChunks));
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (held_ids) { // slab ownership (s2d_halo.hip): only the splats this rank holds, from their compact list
-        if ((uint32_t)i >= *held_count) return;
-        i = (int)held_ids[i];
-    }
-    float* sp = splats + (size_t)i * 9;
-    float* ad = adams + (size_t)i * 18;
-    float* gr = grads + (size_t)i * 9;
-    float v[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-        v[k] = sp[k];
-        if (k < 8 || (optimize_opacity & 1)) { // main.cpp:735-738; bit 1 of the argument: fp32 Adam quotient
-            float m_m = ad[2 * k], m_v = ad[2 * k + 1];
-            v[k] = adam_optimize(m_m, m_v, v[k], gr[k], lr, beta1t, beta2t, (optimize_opacity & 2) != 0);
-            ad[2 * k] = m_m;
-            ad[2 * k + 1] = m_v;
-        }
-        gr[k] = 0.0f;
-    }
+    for (int k = 0; k < 9; k++)
+        if (k < 8 || (mode & 1))
+            v[k] = adam_optimize(mv[2 * k], mv[2 * k + 1], v[k], gr[k], lr, beta1t, beta2t, (mode & 2) != 0);
     // constraints, main.cpp:741-749
     v[0] = glm_clamp(v[0], 0.0f, (float)W - 1.0f);
     v[1] = glm_clamp(v[1], 0.0f, (float)H - 1.0f);
@@ -77,8 +43,6 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
     v[6] = glm_clamp(v[6], 0.0f, 1.0f);
     v[7] = glm_clamp(v[7], 0.0f, 1.0f);
     v[8] = glm_clamp(v[8], 0.1f, 1.0f);
-#pragma unroll
-    for (int k = 0; k < 9; k++) sp[k] = v[k];
     // finite guard, main.cpp:752-785: color.xyz, sx, sy, rot, pos.x (pos.y and opacity are not checked)
     const bool ok = finite_f32(v[5]) && finite_f32(v[6]) && finite_f32(v[7]) && finite_f32(v[2]) &&
                     finite_f32(v[3]) && finite_f32(v[4]) && finite_f32(v[0]);
@@ -86,26 +50,160 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
         atomicOr(&status->nonfinite, 1);
         atomicMin(&status->first_nonfinite_iter, iteration);
     }
-    if (proj) {
-        // A rank that owns a row slab only ever reads the records of splats that can touch its rows.  A splat whose
-        // 3-sigma circle (plus the 1-pixel skirt) stays clear of the slab has an empty exact rectangle, which every
-        // binned rectangle covers: skip its projection (7/8 of the splats at 8 ranks).  NaNs fall through.
-        const float reach = 3.0f * fmaxf(v[2], v[3]) + 2.0f;
-        if (v[1] + reach < (float)g.row_begin || v[1] - reach > (float)g.row_end) {
-            // ... but the re-used tile lists may still name it (it was inside when they were built, and one Adam step
-            // can carry it out by any distance for a large training_rate or loaded moments): leave a record with
-            // an empty row range (begY > endY) behind, so that the raster kernels see no footprint instead of its
-            // stale one.
-            proj[i].q2 = make_float4(v[8], as_f(1), as_f(0), 0.0f);
-            return;
-        }
-        Splat s;
-        s.pos_x = v[0]; s.pos_y = v[1]; s.sx = v[2]; s.sy = v[3]; s.rot = v[4];
-        s.col_r = v[5]; s.col_g = v[6]; s.col_b = v[7]; s.opacity = v[8];
-        const Projected p = project(s);
-        proj[i] = pack_proj(p);
-        if (!rect_still_covers(p, g, rects[i])) raise_rebin(status, check_stamp, host_stamp);
+}
+
+// Projection of the UPDATED splat for the next iteration's raster (main.cpp:423-436, 489-491) and the check against
+// the rectangle its tile lists were built from, so that the next iteration needs no separate pass over the parameters.
+__device__ __forceinline__ void project_updated(const float (&v)[9], int i, const Geometry& g, DeviceStatus* status,
+                                                ProjRec* __restrict__ proj, const TileRect* __restrict__ rects,
+                                                int check_stamp, int* __restrict__ host_stamp)
+{
+    // A rank that owns a row slab only ever reads the records of splats that can touch its rows.  A splat whose
+    // 3-sigma circle (plus the 1-pixel skirt) stays clear of the slab has an empty exact rectangle, which every
+    // binned rectangle covers: skip its projection (7/8 of the splats at 8 ranks).  NaNs fall through.
+    const float reach = 3.0f * fmaxf(v[2], v[3]) + 2.0f;
+    if (v[1] + reach < (float)g.row_begin || v[1] - reach > (float)g.row_end) {
+        // ... but the re-used tile lists may still name it (it was inside when they were built, and one Adam step
+        // can carry it out by any distance for a large training_rate or loaded moments): leave a record with
+        // an empty row range (begY > endY) behind, so that the raster kernels see no footprint instead of its
+        // stale one.
+        proj[i].q2 = make_float4(v[8], as_f(1), as_f(0), 0.0f);
+        return;
     }
+    Splat s;
+    s.pos_x = v[0]; s.pos_y = v[1]; s.sx = v[2]; s.sy = v[3]; s.rot = v[4];
+    s.col_r = v[5]; s.col_g = v[6]; s.col_b = v[7]; s.opacity = v[8];
+    const Projected p = project(s);
+    proj[i] = pack_proj(p);
+    if (!rect_still_covers(p, g, rects[i])) raise_rebin(status, check_stamp, host_stamp);
+}
+
+// The reference abort()s at the first non-finite parameter (main.cpp:752-785): later iterations do nothing.  (Strictly
+// earlier: blocks of the detecting launch itself, which stores `iteration`, must all finish their work.)  Then the MSE of
+// the iteration (main.cpp:796-805) from the tile errors the backward pass left, by the launch's first workgroups
+// (block-uniform: all 256 threads take it together).  Returns false when the launch is to do nothing.
+__device__ __forceinline__ bool adam_prologue(const DeviceStatus* status, int iteration, const SqerrJob& sq)
+{
+    if (status->first_nonfinite_iter < iteration) return false;
+    if (sq.tile_sqerr != nullptr && blockIdx.x < (unsigned)kSqerrChunks)
+        sqerr_reduce(sq.tile_sqerr, sq.num_tiles, sq.out, sq.scratch, (int)blockIdx.x, min((int)gridDim.x, kSqerrChunks));
+    return true;
+}
+
+// One splat per thread, every array accessed record by record: the form for slab OWNERSHIP, where a rank walks the
+// compact list of the splats it holds (s2d_halo.hip) and the records are scattered.  Also re-zeroes the gradient record
+// (main.cpp:550 value-initialises dSplats every iteration).
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, float* __restrict__ adams,
+                                                   float* __restrict__ grads, const uint32_t* __restrict__ held_ids,
+                                                   const uint32_t* __restrict__ held_count, int n, Geometry g,
+                                                   float beta1t,
+                                                   float beta2t, float lr, int mode, int iteration,
+                                                   DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
+                                                   const TileRect* __restrict__ rects, int check_stamp,
+                                                   int* __restrict__ host_stamp, SqerrJob sq)
+{
+    if (!adam_prologue(status, iteration, sq)) return;
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (held_ids) { // only the splats this rank holds, from their compact list
+        if ((uint32_t)i >= *held_count) return;
+        i = (int)held_ids[i];
+    }
+    float* sp = splats + (size_t)i * 9;
+    float* ad = adams + (size_t)i * 18;
+    float* gp = grads + (size_t)i * 9;
+    float v[9], mv[18], gr[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        v[k] = sp[k];
+        gr[k] = gp[k];
+        gp[k] = 0.0f;
+    }
+#pragma unroll
+    for (int k = 0; k < 18; k++) mv[k] = ad[k];
+    adam_update_one(v, mv, gr, g.W, g.H, beta1t, beta2t, lr, mode, iteration, status);
+#pragma unroll
+    for (int k = 0; k < 9; k++) sp[k] = v[k];
+#pragma unroll
+    for (int k = 0; k < 18; k++)
+        if (k < 16 || (mode & 1)) ad[k] = mv[k];
+    if (proj) project_updated(v, i, g, status, proj, rects, check_stamp, host_stamp);
+}
+
+// The same for ALL splats in index order, with every array moved in whole 16-byte lines: a block's 256 records are
+// contiguous (9216 B of parameters, 9216 B of gradients, 18432 B of moments), so the block copies them to LDS with
+// coalesced float4 loads, every thread picks its record out of LDS (stride 9 / 18 dwords), and results go back the
+// same way.  The record-by-record kernel above issues 45 dword loads and 36 dword stores per thread at a 36 / 72 byte
+// lane stride -- 18 to 36 cache lines per instruction -- and ran at 1.8 TB/s (192 us at 10^6 splats); this one is
+// bound by HBM (352 bytes per splat).
+__device__ __forceinline__ void lds_fill(float* lds, const float* __restrict__ src, int floats)
+{
+    const int vec = floats >> 2; // src is 16-byte aligned: a block starts at a multiple of 256 records
+    for (int q = threadIdx.x; q < vec; q += 256) reinterpret_cast<float4*>(lds)[q] = reinterpret_cast<const float4*>(src)[q];
+    for (int q = (vec << 2) + threadIdx.x; q < floats; q += 256) lds[q] = src[q];
+}
+
+__device__ __forceinline__ void lds_drain(float* __restrict__ dst, const float* lds, int floats)
+{
+    const int vec = floats >> 2;
+    for (int q = threadIdx.x; q < vec; q += 256) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(lds)[q];
+    for (int q = (vec << 2) + threadIdx.x; q < floats; q += 256) dst[q] = lds[q];
+}
+
+__global__ __launch_bounds__(256) void adam_staged_kernel(float* __restrict__ splats, float* __restrict__ adams,
+                                                          float* __restrict__ grads, int n, Geometry g, float beta1t,
+                                                          float beta2t, float lr, int mode, int iteration,
+                                                          DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
+                                                          const TileRect* __restrict__ rects, int check_stamp,
+                                                          int* __restrict__ host_stamp, SqerrJob sq)
+{
+    __shared__ __attribute__((aligned(16))) float buf[256 * 18];
+    if (!adam_prologue(status, iteration, sq)) return;
+    const int base = blockIdx.x * 256, cnt = min(256, n - base), t = threadIdx.x;
+    if (cnt <= 0) return;
+    const bool mine = t < cnt;
+    float v[9], mv[18], gr[9];
+    // gradients in, zeros out (main.cpp:550)
+    lds_fill(buf, grads + (size_t)base * 9, cnt * 9);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; k++) gr[k] = mine ? buf[t * 9 + k] : 0.0f;
+    {
+        const int floats = cnt * 9, vec = floats >> 2;
+        float* gp = grads + (size_t)base * 9;
+        for (int q = t; q < vec; q += 256) reinterpret_cast<float4*>(gp)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = (vec << 2) + t; q < floats; q += 256) gp[q] = 0.0f;
+    }
+    __syncthreads();
+    // parameters in
+    lds_fill(buf, splats + (size_t)base * 9, cnt * 9);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 9; k++) v[k] = mine ? buf[t * 9 + k] : 0.0f;
+    __syncthreads();
+    // moments in
+    lds_fill(buf, adams + (size_t)base * 18, cnt * 18);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 18; k++) mv[k] = mine ? buf[t * 18 + k] : 0.0f;
+    if (mine) {
+        adam_update_one(v, mv, gr, g.W, g.H, beta1t, beta2t, lr, mode, iteration, status);
+        // moments out (each thread rewrites only its own record of the block's copy; the opacity slot is written back
+        // unchanged when the checkbox is off)
+#pragma unroll
+        for (int k = 0; k < 18; k++) buf[t * 18 + k] = mv[k];
+    }
+    __syncthreads();
+    lds_drain(adams + (size_t)base * 18, buf, cnt * 18);
+    __syncthreads();
+    // parameters out
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) buf[t * 9 + k] = v[k];
+    }
+    __syncthreads();
+    lds_drain(splats + (size_t)base * 9, buf, cnt * 9);
+    if (proj && mine) project_updated(v, base + t, g, status, proj, rects, check_stamp, host_stamp);
 }
 
 // ref(x,y) = (x/W, 1 - x/W, y/H, 1): main.cpp:261-267's commented generator plus a blue ramp.
@@ -170,8 +268,12 @@ hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t
                        const TileRect* rects, int check_stamp, int* host_stamp, SqerrJob sq, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess; // (callers queue the standalone squared-error reduction themselves when n == 0)
-    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, held_ids, held_count, n, g, beta1t,
-                       beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, sq);
+    if (held_ids == nullptr)
+        hipLaunchKernelGGL(adam_staged_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, n, g, beta1t,
+                           beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, sq);
+    else
+        hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, held_ids, held_count, n, g,
+                           beta1t, beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, sq);
     return hipGetLastError();
 }
 

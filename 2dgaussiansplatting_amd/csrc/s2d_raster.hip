@@ -500,6 +500,11 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
                     n_act += (act_mask >> lane) & 1ull;
                     const int na = __popcll(act_mask);
                     if (lane == 0) atomicAdd(&counters->bwd_lane_hist[na], 1ull);
+                    // how many of the block's four 4x4 quadrants have a live covered pixel (lane = 8*row + column)
+                    const uint32_t lo = (uint32_t)act_mask, hi = (uint32_t)(act_mask >> 32);
+                    const int nq = ((lo & 0x0F0F0F0Fu) != 0u) + ((lo & 0xF0F0F0F0u) != 0u) + ((hi & 0x0F0F0F0Fu) != 0u) +
+                                   ((hi & 0xF0F0F0F0u) != 0u);
+                    if (lane == 0) atomicAdd(&counters->bwd_quadrant_execs, (unsigned long long)nq);
                 }
                 float g_px, g_py, g_sx, g_sy, g_rot, g_r, g_g, g_b, g_op = 0.f;
                 {

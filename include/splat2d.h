@@ -134,6 +134,8 @@ typedef struct s2d_stats {
     int32_t first_nonfinite_iteration; /* -1 if none */
     uint64_t fwd_staged_hit;   /* S2D_CFG_COUNT_PAIRS: staged entries that cover >= 1 pixel of their tile ... */
     uint64_t fwd_rows_hit;     /* ... and (staged entry, tile row) pairs with a non-empty column range (of 16 per entry) */
+    uint64_t bwd_quadrant_execs; /* S2D_CFG_COUNT_PAIRS: bwd_wave_execs weighted by the number (1..4) of 4x4 quadrants of the
+                                  * wave's 8x8 block that hold a live covered pixel */
 } s2d_stats;
 
 typedef struct s2d_ctx s2d_ctx;
@@ -212,8 +214,8 @@ int s2d_grads_combine(s2d_ctx* ctx, const int32_t* rows_device, int32_t n_rows, 
 
 /* ---- multi-GPU plumbing (one process per GPU; the host all-reduces between backward and Adam) ---- */
 /* Use caller-owned DEVICE memory (n_splats * 9 floats, layout s2d_splat[n]) as the gradient buffer, so the host
- * can all-reduce it in place (RCCL).  NULL -> back to the context's own buffer.  The buffer must be zero when
- * bound and is re-zeroed by s2d_adam_step. */
+ * can all-reduce it in place (RCCL).  NULL -> back to the context's own buffer.  The buffer must be 16-byte
+ * aligned, zero when bound, and is re-zeroed by s2d_adam_step. */
 int s2d_bind_grads_device(s2d_ctx* ctx, void* grads_device);
 /* Device address of the gradient buffer currently in use. */
 void* s2d_grads_device_ptr(s2d_ctx* ctx);

@@ -32,3 +32,6 @@ tot = h.sum()
 cum = np.cumsum(h) / tot
 work = np.cumsum(h * np.arange(65)) / (h * np.arange(65)).sum()
 print("bwd execs by active lanes: " + "  ".join("<=%d: %.0f%% of execs, %.0f%% of lane-work" % (k, 100 * cum[k], 100 * work[k]) for k in (4, 8, 16, 24, 32, 48, 63)))
+q = st["bwd_quadrant_execs"] / max(st["bwd_wave_execs"], 1)
+print("bwd: %.2f of 4 quadrants (4x4 pixels) live per executed (wave, entry): %.1f live lanes per live quadrant; "
+      "quadrant-granular execution would need %.0f%% of the lane-slots" % (q, st["bwd_active"] / max(st["bwd_quadrant_execs"], 1), 100.0 * q / 4))

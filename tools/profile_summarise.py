@@ -4,6 +4,13 @@
   kernel stats : profile_summarise.py stats  <dir> <out.csv>      (copies the *_kernel_stats.csv of --kernel-trace --stats)
   counters     : profile_summarise.py pmc    <dir> [<dir> ...] <out.csv>
                  per kernel name: launches and the per-launch mean of every counter found in *_counter_collection.csv
+  working      : profile_summarise.py working <dir> <out.csv>
+                 per kernel, from the kernel TRACE: all launches, and the launches that did work -- the first raster kernel of
+                 an iteration is launched optimistically and returns at once (~22 us) when the tile lists turn out stale
+                 (csrc/s2d_api.hip queue_raster), so the stats file's AverageNs mixes in one void launch per list rebuild
+  traffic      : profile_summarise.py traffic <pmc_traffic.csv> <traffic.json>
+                 HBM bytes per launch of the dominant raster kernel for bench.py's roofline.traffic, corrected as
+                 /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950, and tied to the kernel sources
 """
 import csv, glob, os, sys
 from collections import defaultdict
@@ -46,6 +53,51 @@ def main():
                 n = max(len(cnt[k][c]) for c in cnt[k])
                 g.write("%s,%d,%s\n" % (k.replace(",", ";"), n, ",".join("%.6g" % (acc[k][c] / max(len(cnt[k][c]), 1)) if c in acc[k] else "" for c in counters)))
         print("wrote", out)
+    elif mode == "working":
+        import statistics
+        per = defaultdict(list)
+        with open(find(sys.argv[2], "kernel_trace.csv")) as f:
+            for row in csv.DictReader(f):
+                per[short(row["Kernel_Name"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+        with open(sys.argv[3], "w") as g:
+            g.write("# from the kernel trace; a launch is 'void' when shorter than 5 % of the kernel's median duration\n")
+            g.write("kernel,launches,average_ns_all,void_launches,working_launches,average_ns_working,median_ns_working\n")
+            for k in sorted(per, key=lambda k: -sum(per[k])):
+                d = per[k]
+                med = statistics.median(d)
+                work = [x for x in d if x >= 0.05 * med]
+                g.write("%s,%d,%.0f,%d,%d,%.0f,%.0f\n" % (k.replace(",", ";"), len(d), sum(d) / len(d), len(d) - len(work), len(work),
+                                                       sum(work) / len(work), statistics.median(work)))
+        print("wrote", sys.argv[3])
+    elif mode == "traffic":
+        import hashlib, json
+        rows = [r for r in csv.reader(l for l in open(sys.argv[2]) if not l.startswith("#"))]
+        hdr, rows = rows[0], rows[1:]
+        ifetch, iwrite = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE")
+        cand = [r for r in rows if "raster_fused_kernel<false; false; false; false>" in r[0]] or [r for r in rows if "raster_" in r[0]]
+        r = max(cand, key=lambda r: int(r[1]))
+        fetch_kb, write_kb = float(r[ifetch]), float(r[iwrite])
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        d = os.path.join(root, "2dgaussiansplatting_amd", "csrc")
+        h = hashlib.sha256()
+        for name in sorted(os.listdir(d)):
+            if name.endswith((".hip", ".h", ".inc")):
+                h.update(name.encode())
+                h.update(open(os.path.join(d, name), "rb").read())
+        out = {
+            "source": "%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes; tools/gpu_profile_round.sh)" % os.path.basename(sys.argv[2]),
+            "workload": "4096x4096 synthetic, 1,000,000 Gaussians, 1 GPU (python3 bench.py)",
+            "kernel": r[0], "launches": int(r[1]),
+            "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
+            "correction": "gfx950: FETCH_SIZE tallies a 128-B request of a wide coalesced read as 64 B, WRITE_SIZE is exact for 16-B "
+                          "streaming stores and float atomics: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section); "
+                          "this kernel also makes 8-B mask accesses and 64-B record gathers, widths the guide calls uncalibrated, so the "
+                          "figure is an upper estimate",
+            "dominant_kernel_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
+            "kernel_source_digest": h.hexdigest()[:16],
+        }
+        json.dump(out, open(sys.argv[3], "w"), indent=1)
+        print("wrote", sys.argv[3])
     else:
         raise SystemExit(__doc__)
 
