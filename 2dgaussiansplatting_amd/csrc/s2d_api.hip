@@ -265,8 +265,9 @@ int queue_raster(s2d_ctx* c, const RasterJob& job)
 
 int queue_forward(s2d_ctx* c) { return queue_raster(c, RasterJob{}); }
 
-// Sum of the tile errors of the backward pass just queued -> ring slot of this iteration.  defer: leave it to the Adam
-// launch that the caller queues next (s2d_step), whose first workgroups do it on the way (one dispatch less).
+// Sum of the tile errors of the backward pass just queued -> ring slot of this iteration.  defer: leave it to the next
+// Adam launch, whose first workgroups do it on the way (one dispatch less per iteration); whoever wants the value
+// before that (s2d_get_mse, s2d_get_sqerr_trace) flushes it with the standalone kernel (flush_sqerr).
 int queue_sqerr(s2d_ctx* c, bool defer = false)
 {
     const int slot = c->iterations % c->trace_cap;
@@ -296,9 +297,18 @@ int queue_backward(s2d_ctx* c, bool need_opacity_grad)
     return queue_sqerr(c);
 }
 
+int flush_sqerr(s2d_ctx* c)
+{
+    if (!c->sqerr_deferred) return S2D_OK;
+    c->sqerr_deferred = false;
+    S2D_HIP(c, launch_sqerr_finalize(c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + c->last_sqerr_slot,
+                                     c->d_tile_sqerr + c->g.num_tiles, c->d_status, c->iterations, c->stream));
+    return S2D_OK;
+}
+
 // Forward + backward (+ squared error) of the current parameters through the fused kernel.  Pair counting is a
 // property of the separate kernels only, so a counting context takes those.
-int queue_forward_backward(s2d_ctx* c, bool need_opacity_grad, bool write_image, bool defer_sqerr = false)
+int queue_forward_backward(s2d_ctx* c, bool need_opacity_grad, bool write_image, bool defer_sqerr = true)
 {
     if (c->cfg.flags & S2D_CFG_COUNT_PAIRS) {
         if (int rc = queue_forward(c)) return rc;
@@ -524,6 +534,7 @@ int s2d_init_splats(s2d_ctx* c)
 {
     if (!c) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
+    if (int rc = flush_sqerr(c)) return rc;
     S2D_HIP(c, launch_init_splats(c->d_splats, c->d_adams, c->n, c->g.W, c->g.H, c->stream));
     if (c->n > 0) S2D_HIP(c, hipMemsetAsync(c->d_grads, 0, (size_t)c->n * 9 * sizeof(float), c->stream));
     if (int rc = reset_status(c)) return rc;
@@ -562,6 +573,7 @@ int s2d_set_adam(s2d_ctx* c, const s2d_splat_adam* adams, float beta1t, float be
 {
     if (!c || (!adams && c->n) || iterations < 0) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
+    if (int rc = flush_sqerr(c)) return rc; // (its ring slot is named by the iteration count about to change)
     S2D_HIP(c, hipMemcpyAsync(c->d_adams, adams, (size_t)c->n * sizeof(s2d_splat_adam), hipMemcpyHostToDevice, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
     c->beta1t = c->good_beta1t = beta1t;
@@ -679,6 +691,7 @@ int s2d_get_mse(s2d_ctx* c, double* mse)
     if (!c || !mse) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
     if (c->last_sqerr_slot < 0) return fail(c, S2D_E_STATE, "no backward pass has run yet");
+    if (int rc = flush_sqerr(c)) return rc;
     double v = 0.0;
     S2D_HIP(c, hipMemcpyAsync(&v, c->d_sqerr_trace + c->last_sqerr_slot, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
@@ -783,6 +796,7 @@ int s2d_get_sqerr_trace(s2d_ctx* c, int32_t first_iteration, int32_t count, doub
 {
     if (!c || !out || count < 0 || first_iteration < 0 || count > c->trace_cap) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
+    if (int rc = flush_sqerr(c)) return rc;
     int done = 0;
     while (done < count) {
         const int slot = (first_iteration + done) % c->trace_cap;

@@ -90,111 +90,99 @@ __device__ __forceinline__ bool adam_prologue(const DeviceStatus* status, int it
     return true;
 }
 
-// One splat per thread, every array accessed record by record: the form for slab OWNERSHIP, where a rank walks the
-// compact list of the splats it holds (s2d_halo.hip) and the records are scattered.  Also re-zeroes the gradient record
-// (main.cpp:550 value-initialises dSplats every iteration).
+// Adam launch: one splat per thread, 256 records per block, every array moved through LDS so that global memory is
+// accessed in runs of consecutive dwords instead of one record per lane.  (A thread reading its own 36-byte record
+// dword by dword makes every load instruction touch 18 cache lines per wave, 36 for the 72-byte moments: the
+// record-by-record form of this kernel ran at 1.8 TB/s, 192 us at 10^6 splats.)
+//   * all splats in index order (ids == nullptr): a block's records are contiguous -- whole float4 lines;
+//   * slab OWNERSHIP (s2d_halo.hip): the block walks 256 entries of the rank's compact, ascending list of held splats;
+//     element e of the block's copy is dword e % w of record ids[e / w], so consecutive lanes still read consecutive
+//     dwords of a record (and usually of neighbouring records).
+// Also re-zeroes the gradient records (main.cpp:550 value-initialises dSplats every iteration).
+template <int WIDTH>
+__device__ __forceinline__ void lds_fill(float* lds, const float* __restrict__ src, const uint32_t* s_ids, int base, int cnt)
+{
+    const int floats = cnt * WIDTH;
+    if (s_ids == nullptr) { // contiguous and 16-byte aligned: a block starts at a multiple of 256 records
+        const float* p = src + (size_t)base * WIDTH;
+        const int vec = floats >> 2;
+        for (int q = threadIdx.x; q < vec; q += 256) reinterpret_cast<float4*>(lds)[q] = reinterpret_cast<const float4*>(p)[q];
+        for (int q = (vec << 2) + threadIdx.x; q < floats; q += 256) lds[q] = p[q];
+    } else {
+        for (int q = threadIdx.x; q < floats; q += 256) lds[q] = src[(size_t)s_ids[q / WIDTH] * WIDTH + q % WIDTH];
+    }
+}
+
+template <int WIDTH>
+__device__ __forceinline__ void lds_drain(float* __restrict__ dst, const float* lds, const uint32_t* s_ids, int base, int cnt)
+{
+    const int floats = cnt * WIDTH;
+    if (s_ids == nullptr) {
+        float* p = dst + (size_t)base * WIDTH;
+        const int vec = floats >> 2;
+        for (int q = threadIdx.x; q < vec; q += 256) reinterpret_cast<float4*>(p)[q] = reinterpret_cast<const float4*>(lds)[q];
+        for (int q = (vec << 2) + threadIdx.x; q < floats; q += 256) p[q] = lds[q];
+    } else {
+        for (int q = threadIdx.x; q < floats; q += 256) dst[(size_t)s_ids[q / WIDTH] * WIDTH + q % WIDTH] = lds[q];
+    }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, float* __restrict__ adams,
                                                    float* __restrict__ grads, const uint32_t* __restrict__ held_ids,
                                                    const uint32_t* __restrict__ held_count, int n, Geometry g,
-                                                   float beta1t,
-                                                   float beta2t, float lr, int mode, int iteration,
+                                                   float beta1t, float beta2t, float lr, int mode, int iteration,
                                                    DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
                                                    const TileRect* __restrict__ rects, int check_stamp,
                                                    int* __restrict__ host_stamp, SqerrJob sq)
 {
-    if (!adam_prologue(status, iteration, sq)) return;
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (held_ids) { // only the splats this rank holds, from their compact list
-        if ((uint32_t)i >= *held_count) return;
-        i = (int)held_ids[i];
-    }
-    float* sp = splats + (size_t)i * 9;
-    float* ad = adams + (size_t)i * 18;
-    float* gp = grads + (size_t)i * 9;
-    float v[9], mv[18], gr[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-        v[k] = sp[k];
-        gr[k] = gp[k];
-        gp[k] = 0.0f;
-    }
-#pragma unroll
-    for (int k = 0; k < 18; k++) mv[k] = ad[k];
-    adam_update_one(v, mv, gr, g.W, g.H, beta1t, beta2t, lr, mode, iteration, status);
-#pragma unroll
-    for (int k = 0; k < 9; k++) sp[k] = v[k];
-#pragma unroll
-    for (int k = 0; k < 18; k++)
-        if (k < 16 || (mode & 1)) ad[k] = mv[k];
-    if (proj) project_updated(v, i, g, status, proj, rects, check_stamp, host_stamp);
-}
-
-// The same for ALL splats in index order, with every array moved in whole 16-byte lines: a block's 256 records are
-// contiguous (9216 B of parameters, 9216 B of gradients, 18432 B of moments), so the block copies them to LDS with
-// coalesced float4 loads, every thread picks its record out of LDS (stride 9 / 18 dwords), and results go back the
-// same way.  The record-by-record kernel above issues 45 dword loads and 36 dword stores per thread at a 36 / 72 byte
-// lane stride -- 18 to 36 cache lines per instruction -- and ran at 1.8 TB/s (192 us at 10^6 splats); this one is
-// bound by HBM (352 bytes per splat).
-__device__ __forceinline__ void lds_fill(float* lds, const float* __restrict__ src, int floats)
-{
-    const int vec = floats >> 2; // src is 16-byte aligned: a block starts at a multiple of 256 records
-    for (int q = threadIdx.x; q < vec; q += 256) reinterpret_cast<float4*>(lds)[q] = reinterpret_cast<const float4*>(src)[q];
-    for (int q = (vec << 2) + threadIdx.x; q < floats; q += 256) lds[q] = src[q];
-}
-
-__device__ __forceinline__ void lds_drain(float* __restrict__ dst, const float* lds, int floats)
-{
-    const int vec = floats >> 2;
-    for (int q = threadIdx.x; q < vec; q += 256) reinterpret_cast<float4*>(dst)[q] = reinterpret_cast<const float4*>(lds)[q];
-    for (int q = (vec << 2) + threadIdx.x; q < floats; q += 256) dst[q] = lds[q];
-}
-
-__global__ __launch_bounds__(256) void adam_staged_kernel(float* __restrict__ splats, float* __restrict__ adams,
-                                                          float* __restrict__ grads, int n, Geometry g, float beta1t,
-                                                          float beta2t, float lr, int mode, int iteration,
-                                                          DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
-                                                          const TileRect* __restrict__ rects, int check_stamp,
-                                                          int* __restrict__ host_stamp, SqerrJob sq)
-{
     __shared__ __attribute__((aligned(16))) float buf[256 * 18];
+    __shared__ uint32_t s_idbuf[256];
     if (!adam_prologue(status, iteration, sq)) return;
-    const int base = blockIdx.x * 256, cnt = min(256, n - base), t = threadIdx.x;
+    const int total = held_ids ? (int)min(*held_count, (uint32_t)n) : n;
+    const int base = blockIdx.x * 256, cnt = min(256, total - base), t = threadIdx.x;
     if (cnt <= 0) return;
     const bool mine = t < cnt;
+    const uint32_t* s_ids = nullptr;
+    int i = base + t;
+    if (held_ids) { // only the splats this rank holds, from their compact list
+        if (mine) {
+            i = (int)held_ids[base + t];
+            s_idbuf[t] = (uint32_t)i;
+        }
+        s_ids = s_idbuf;
+        __syncthreads();
+    }
     float v[9], mv[18], gr[9];
-    // gradients in, zeros out (main.cpp:550)
-    lds_fill(buf, grads + (size_t)base * 9, cnt * 9);
+    // gradients in, zeros out
+    lds_fill<9>(buf, grads, s_ids, base, cnt);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 9; k++) gr[k] = mine ? buf[t * 9 + k] : 0.0f;
-    {
-        const int floats = cnt * 9, vec = floats >> 2;
-        float* gp = grads + (size_t)base * 9;
-        for (int q = t; q < vec; q += 256) reinterpret_cast<float4*>(gp)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q = (vec << 2) + t; q < floats; q += 256) gp[q] = 0.0f;
-    }
+    __syncthreads();
+    for (int q = t; q < 256 * 9 / 4; q += 256) reinterpret_cast<float4*>(buf)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    lds_drain<9>(grads, buf, s_ids, base, cnt);
     __syncthreads();
     // parameters in
-    lds_fill(buf, splats + (size_t)base * 9, cnt * 9);
+    lds_fill<9>(buf, splats, s_ids, base, cnt);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 9; k++) v[k] = mine ? buf[t * 9 + k] : 0.0f;
     __syncthreads();
     // moments in
-    lds_fill(buf, adams + (size_t)base * 18, cnt * 18);
+    lds_fill<18>(buf, adams, s_ids, base, cnt);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 18; k++) mv[k] = mine ? buf[t * 18 + k] : 0.0f;
     if (mine) {
         adam_update_one(v, mv, gr, g.W, g.H, beta1t, beta2t, lr, mode, iteration, status);
-        // moments out (each thread rewrites only its own record of the block's copy; the opacity slot is written back
+        // moments out (each thread rewrites only its own record of the block's copy; the opacity slot goes back
         // unchanged when the checkbox is off)
 #pragma unroll
         for (int k = 0; k < 18; k++) buf[t * 18 + k] = mv[k];
     }
     __syncthreads();
-    lds_drain(adams + (size_t)base * 18, buf, cnt * 18);
+    lds_drain<18>(adams, buf, s_ids, base, cnt);
     __syncthreads();
     // parameters out
     if (mine) {
@@ -202,8 +190,8 @@ __global__ __launch_bounds__(256) void adam_staged_kernel(float* __restrict__ sp
         for (int k = 0; k < 9; k++) buf[t * 9 + k] = v[k];
     }
     __syncthreads();
-    lds_drain(splats + (size_t)base * 9, buf, cnt * 9);
-    if (proj && mine) project_updated(v, base + t, g, status, proj, rects, check_stamp, host_stamp);
+    lds_drain<9>(splats, buf, s_ids, base, cnt);
+    if (proj && mine) project_updated(v, i, g, status, proj, rects, check_stamp, host_stamp);
 }
 
 // ref(x,y) = (x/W, 1 - x/W, y/H, 1): main.cpp:261-267's commented generator plus a blue ramp.
@@ -268,12 +256,8 @@ hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t
                        const TileRect* rects, int check_stamp, int* host_stamp, SqerrJob sq, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess; // (callers queue the standalone squared-error reduction themselves when n == 0)
-    if (held_ids == nullptr)
-        hipLaunchKernelGGL(adam_staged_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, n, g, beta1t,
-                           beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, sq);
-    else
-        hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, held_ids, held_count, n, g,
-                           beta1t, beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, sq);
+    hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, held_ids, held_count, n, g,
+                       beta1t, beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, sq);
     return hipGetLastError();
 }
 
