@@ -30,6 +30,7 @@ S2D_CFG_DETERMINISTIC = 0x4
 S2D_CFG_EXACT_EXP = 0x8
 S2D_CFG_ADAM_FP32 = 0x10
 S2D_BWD_SKIP_OPACITY_GRAD = 0x1
+S2D_FB_SKIP_IMAGE = 0x2
 STATUS_NAMES = {0: "S2D_OK", 1: "S2D_E_INVALID", 2: "S2D_E_HIP", 3: "S2D_E_NONFINITE", 4: "S2D_E_NOMEM",
                 5: "S2D_E_STATE"}
 
@@ -253,11 +254,13 @@ class Trainer:
             skip_opacity_grad = self.lean_backward and not self.optimize_opacity
         self._ck(self.L.s2d_backward(self._h, S2D_BWD_SKIP_OPACITY_GRAD if skip_opacity_grad else 0))
 
-    def forward_backward(self, skip_opacity_grad=None):
-        """forward() + backward() in one launch per tile (same results); flags as backward()."""
+    def forward_backward(self, skip_opacity_grad=None, skip_image=False):
+        """forward() + backward() in one launch per tile (same results); skip_opacity_grad as backward();
+        skip_image: do not store image0 (S2D_FB_SKIP_IMAGE)."""
         if skip_opacity_grad is None:
             skip_opacity_grad = self.lean_backward and not self.optimize_opacity
-        self._ck(self.L.s2d_forward_backward(self._h, S2D_BWD_SKIP_OPACITY_GRAD if skip_opacity_grad else 0))
+        self._ck(self.L.s2d_forward_backward(self._h, (S2D_BWD_SKIP_OPACITY_GRAD if skip_opacity_grad else 0) |
+                                             (S2D_FB_SKIP_IMAGE if skip_image else 0)))
 
     def get_grads(self):
         a = np.zeros(self.n, dtype=SPLAT_DTYPE)

@@ -627,7 +627,7 @@ int s2d_forward_backward(s2d_ctx* c, uint32_t flags)
 {
     if (!c) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
-    return queue_forward_backward(c, !(flags & S2D_BWD_SKIP_OPACITY_GRAD), true);
+    return queue_forward_backward(c, !(flags & S2D_BWD_SKIP_OPACITY_GRAD), !(flags & S2D_FB_SKIP_IMAGE));
 }
 
 int s2d_backward(s2d_ctx* c, uint32_t flags)

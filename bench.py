@@ -244,12 +244,14 @@ def main():
     dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     done = t.stats()["iterations"]
     first = done - args.steps
-    # PSNR after a fixed 200 iterations: keep training, untimed, up to iteration 200
+    # PSNR after a fixed 200 iterations: keep training, untimed, up to iteration 200, and
+    # read iteration 199's squared error from the device-side trace ring (it holds the last 65536 iterations)
     extra = max(0, 200 - done)
     for _ in range(extra):
         one_step()
     torch.cuda.synchronize()
-    sq200 = torch.from_numpy(t.sqerr_trace(max(done + extra - 1, 0), 1)).cuda() if done + extra > 0 else None
+    psnr_iter = 199 if done + extra - 200 < 60000 else done + extra - 1
+    sq200 = torch.from_numpy(t.sqerr_trace(psnr_iter, 1)).cuda()
     if dist is not None and sq200 is not None:
         D.reduce_sqerr(sq200, dist)
     sq = torch.from_numpy(t.sqerr_trace(first, args.steps)).cuda()
@@ -296,9 +298,8 @@ def main():
         rp = os.path.join(ROOT, "tests", "golden", "bench_reference_trace.json")
         if os.path.exists(rp):
             rj = json.load(open(rp))
-            it199 = done + extra - 1
-            if (rj["width"], rj["height"], rj["n_splats"]) == (W, H, n) and 0 <= it199 < len(rj["mse"]):
-                psnr_ref = 10.0 * float(np.log10(255.0 ** 2 / rj["mse"][it199]))
+            if (rj["width"], rj["height"], rj["n_splats"]) == (W, H, n) and 0 <= psnr_iter < len(rj["mse"]):
+                psnr_ref = 10.0 * float(np.log10(255.0 ** 2 / rj["mse"][psnr_iter]))
         psnr_gpu = (10.0 * float(np.log10(255.0 ** 2 / (float(sq200[0].item()) / (H * W * 3)))) if sq200 is not None and float(sq200[0].item()) > 0 else None)
         steady = step_ms[~rebuilds] if (~rebuilds).any() else step_ms
         out = {
@@ -326,7 +327,7 @@ def main():
                        "rebin_interval": args.rebin_interval},
             "mse_last": mse_last,
             "psnr_db_last": (10.0 * float(np.log10(255.0 ** 2 / mse_last)) if mse_last > 0 else None),
-            "psnr_db_at_iteration": done + extra - 1,
+            "psnr_db_at_iteration": psnr_iter,
             "psnr_db": psnr_gpu,
             "psnr_ref_db": psnr_ref,  # the CPU oracle (reference loop) at the same iteration of the same workload
             "psnr_delta_db": (psnr_gpu - psnr_ref) if (psnr_gpu is not None and psnr_ref is not None) else None,

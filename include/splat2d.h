@@ -101,6 +101,9 @@ typedef enum s2d_status {
                                   * vectors pin.  The two differ by <= 1 ulp of the parameter
                                   * + ~3 ulp of the update per step; 100-iteration traces by a few 1e-4 (test_oracle_kat.py). */
 
+#define S2D_FB_SKIP_IMAGE 0x2u /* s2d_forward_backward only: do not store image0 (the backward walk takes the final colours from
+                                * registers); s2d_get_image then returns an older frame.  For training loops that never look. */
+
 typedef struct s2d_config {
     uint32_t struct_size;   /* = sizeof(s2d_config) */
     int32_t width, height;  /* imageRef.width(), .height() (main.cpp:254) */
@@ -170,7 +173,7 @@ int s2d_get_image(s2d_ctx* ctx, float* rgba32f);
 int s2d_backward(s2d_ctx* ctx, uint32_t flags);
 /* s2d_forward + s2d_backward in one kernel launch per tile (same results: a tile's backward walk needs only its own
  * pixels' final colours).  What s2d_step queues; for callers that put their own work between backward and Adam (the
- * multi-GPU exchange).  flags as s2d_backward. */
+ * multi-GPU exchange).  flags: S2D_BWD_SKIP_OPACITY_GRAD, S2D_FB_SKIP_IMAGE. */
 int s2d_forward_backward(s2d_ctx* ctx, uint32_t flags);
 int s2d_get_grads(s2d_ctx* ctx, s2d_splat* dsplats);
 

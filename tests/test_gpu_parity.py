@@ -1070,3 +1070,21 @@ def test_cpp_host_multi_gpu_path_through_rccl_on_one_gpu():
     # more ranks than this box has GPUs: a clean error, not a crash
     p = subprocess.run(args + ["--gpus", "2"], capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and p.stdout.strip() == ""
+
+
+def test_forward_backward_skip_image_flag():
+    """S2D_FB_SKIP_IMAGE: same gradients and squared error, image0 left as it was."""
+    tgt = mini_target()
+    o, t = make_pair(tgt, 2000, 2, deterministic=True)
+    t.forward()
+    old = t.get_image()
+    t.backward()
+    g0, m0 = t.get_grads().tobytes(), t.mse()
+    t.adam_step()
+    o2, t2 = make_pair(tgt, 2000, 2, deterministic=True)
+    t2.forward_backward(skip_image=True)
+    assert t2.get_grads().tobytes() == g0 and t2.mse() == m0
+    assert not t2.get_image().any()               # never stored in this context
+    t.forward_backward(skip_image=True)           # a step later: the old frame stays
+    assert t.get_image().tobytes() == old.tobytes()
+    t.close(); t2.close()
