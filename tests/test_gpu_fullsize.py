@@ -202,12 +202,14 @@ def test_window_gradients_and_step_after_training(case, iters):
     assert err.max() <= STEP_REL, err.max()
 
 
-@pytest.mark.parametrize("steps", [2, 20])
-def test_native_535x426_50k_gradients_and_step(steps):
-    """BASELINE configs[1] at the file's native size (the dense case: 4.9 % of the visited pairs are active, the worst
-    S/(1-alpha) cancellation, main.cpp:627-628): ALL 50 000 gradients to the three bars and one optimiser step on the
-    update, from the oracle's state after `steps` iterations."""
-    tgt = O.target_rgba32f(O.load_s2di(os.path.join(O.GOLDEN, "squirrel_cls_535x426.s2di")))
+@pytest.mark.parametrize("image,steps", [("squirrel_cls_535x426", 2), ("squirrel_cls_535x426", 20),
+                                         ("squirrel_cls_512x512", 2), ("squirrel_cls_512x512", 20)])
+def test_cfg1_50k_gradients_and_step(image, steps):
+    """BASELINE configs[1] -- at the file's native 535x426 and as the 512x512 the config names (centre crop + Lanczos,
+    tools/make_image_fixtures.py) -- the dense case: 4.9 % of the visited pairs are active, the worst S/(1-alpha)
+    cancellation (main.cpp:627-628).  ALL 50 000 gradients to the three bars and one optimiser step on the update,
+    from the oracle's state after `steps` iterations."""
+    tgt = O.target_rgba32f(O.load_s2di(os.path.join(O.GOLDEN, image + ".s2di")))
     n = 50_000
     o = O.OracleTrainer(tgt, n)
     for _ in range(steps):
@@ -226,7 +228,7 @@ def test_native_535x426_50k_gradients_and_step(steps):
         assert o.adam() == 0
         err = O.step_delta_error(before, t.get_splats().view(np.float32).reshape(-1, 9), o.splats.view(np.float32).reshape(-1, 9))
     st["step_delta_over_lr"] = float(err.max())
-    _report("native 535x426/50k after %d iterations" % steps, st)
+    _report("cfg1 %s/50k after %d iterations" % (image.split("_")[-1], steps), st)
     assert err.max() <= STEP_REL, err.max()
 
 
@@ -271,3 +273,65 @@ def test_bench_plain_command_two_ranks_gloo():
         assert out["exchange_rank0"]["scheme"] == exchange
         psnr[exchange] = out["psnr_db"]
     assert abs(psnr["halo"] - psnr["dense"]) < 0.05
+
+
+def _fp16(a):
+    return a.astype(np.float16).astype(np.float32)
+
+
+def test_cfg5_8192_4m_fp16_window_matches_oracle_on_rounded_images():
+    """BASELINE configs[4] (8192x8192, 4 000 000 Gaussians, fp16 colour / fp32 gradients) on one GPU: after 3 iterations
+    a 256x256 window of the fp16 framebuffer equals, bit for bit, the oracle's rounded to fp16, and the gradients of
+    the splats inside the window meet the three bars against the oracle fed the rounded target and framebuffer."""
+    W = H = 8192
+    n = 4_000_000
+    win = (4100, 3000, 256, 256)
+    x0, y0, w, h = win
+    tgt = _fp16(O.synthetic_target(W, H))
+    with S2D.Trainer(W, H, n, fp16_images=True) as t:
+        t.set_target_synthetic()
+        t.init()
+        t.step(3)
+        s = t.get_splats()
+        t.forward()
+        img = t.get_image()
+        t.backward()
+        g = t.get_grads().view(np.float32).reshape(-1, 9)
+    wo = O.WindowOracle(tgt, s.view(O.SPLAT_DTYPE), win)
+    o = wo.o
+    r0, r1 = wo.rows()
+    want = _fp16(o.forward(r0, r1)[y0:y0 + h, x0:x0 + w])
+    assert img[y0:y0 + h, x0:x0 + w].tobytes() == want.tobytes()
+    o.image0[r0:r1] = _fp16(o.image0[r0:r1])      # the backward pass reads the stored (rounded) framebuffer
+    o.dsplats[:] = 0
+    dsum = np.zeros((o.n, 9)); dabs = np.zeros((o.n, 9))
+    o.L.s2do_backward_rows_stats(o.splats.ctypes.data, o.n, o.W, o.H, r0, r1, o.image0.ctypes.data, o.ref.ctypes.data,
+                                 o.image1.ctypes.data, o.dsplats.ctypes.data, dsum.ctypes.data, dabs.ctypes.data)
+    li = wo.local_inside
+    st = O.grad_bars(g[wo.inside], o.dsplats.view(np.float32).reshape(-1, 9)[li], dsum[li], dabs[li])
+    st["inside"] = len(li)
+    _report("window cfg5 8192^2/4M fp16 images it3", st)
+    assert len(li) > 1500
+
+
+def test_pair_count_beyond_32_bits_is_reported_not_wrapped():
+    """70 000 splats at the sx/sy clamp cover all 65 536 tiles of a 4096^2 image each: 4.6e9 (tile, splat) pairs.  The
+    32-bit scan saturates instead of wrapping to a small number, and the forward pass fails with S2D_E_NOMEM rather
+    than rendering from truncated lists."""
+    n = 70_000
+    s = np.zeros(n, dtype=S2D.SPLAT_DTYPE)
+    s["pos"] = 2048.0
+    s["sx"] = s["sy"] = 1024.0
+    s["color"] = 0.5
+    s["opacity"] = 0.5
+    with S2D.Trainer(4096, 4096, n) as t:
+        t.set_target_synthetic()
+        t.set_splats(s)
+        with pytest.raises(S2D.S2DError) as ei:
+            t.forward()
+        assert ei.value.code == 4   # S2D_E_NOMEM
+        s["sx"][1000:] = 2.0
+        s["sy"][1000:] = 2.0
+        t.set_splats(s)             # 1 000 image-covering splats still fit
+        t.forward()
+        assert np.isfinite(t.get_image()).all()
