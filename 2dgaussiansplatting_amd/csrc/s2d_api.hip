@@ -181,7 +181,7 @@ int rebuild_lists(s2d_ctx* c)
         return fail(c, S2D_E_NOMEM, "tile lists need more than 2^32 - 65536 (tile, splat) pairs");
     int rc = ensure_pair_capacity(c, total);
     if (rc != S2D_OK) return rc;
-    S2D_HIP(c, launch_emit_pairs(c->d_rects, c->d_offsets, n, c->g, c->d_keys[0], c->d_vals[0],
+    S2D_HIP(c, launch_emit_pairs(c->d_rects, c->d_offsets, c->d_counts, n, c->g, c->d_keys[0], c->d_vals[0],
                                  (uint32_t)c->pair_capacity, c->stream));
     uint32_t *k_out = nullptr, *v_out = nullptr;
     S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)total,

@@ -142,7 +142,7 @@ hipError_t sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, 
 hipError_t launch_project(const float* splats, const uint8_t* held, int n, Geometry g, float margin, int mode, ProjRec* proj,
                           TileRect* rects, uint32_t* counts, DeviceStatus* status, int check_stamp, int* host_stamp,
                           hipStream_t stream);
-hipError_t launch_emit_pairs(const TileRect* rects, const uint32_t* offsets, int n, Geometry g,
+hipError_t launch_emit_pairs(const TileRect* rects, const uint32_t* offsets, const uint32_t* counts, int n, Geometry g,
                              uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream);
 hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, int num_tiles,
                                uint32_t* tile_off, hipStream_t stream);
