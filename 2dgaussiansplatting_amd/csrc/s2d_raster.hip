@@ -227,7 +227,10 @@ __device__ __forceinline__ void forward_tile(FwdShared& s, const TileCtx& c, con
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
         if (alive_mask != 0ull || COUNT) {
             const unsigned long long my_mask = (lane < cnt) ? s.mask[w * B + lane] : 0ull;
-            unsigned long long cand = __ballot(my_mask != 0ull); // entries that touch this wave's block at all
+            // entries that touch a pixel of this wave's block that is still alive now (the counting build walks
+            // every entry that touches the block at all, for its "visited" statistic); pixels only ever die, so
+            // nothing is missed, and the per-entry test below still sees the mask of the moment
+            unsigned long long cand = __ballot(COUNT ? my_mask != 0ull : (my_mask & alive_mask) != 0ull);
             while (cand != 0ull) {
                 const int e = __builtin_ctzll(cand);
                 cand &= cand - 1ull;
@@ -482,7 +485,7 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
         unsigned long long touched = 0ull;
         if (alive_mask != 0ull || COUNT) {
             const unsigned long long my_mask = (lane < cnt) ? s.mask[w * B + lane] : 0ull;
-            unsigned long long cand = __ballot(my_mask != 0ull);
+            unsigned long long cand = __ballot(COUNT ? my_mask != 0ull : (my_mask & alive_mask) != 0ull); // as in the forward walk
             while (cand != 0ull) {
                 const int e = __builtin_ctzll(cand);
                 cand &= cand - 1ull;
