@@ -180,7 +180,20 @@ __device__ __forceinline__ TileCtx tile_ctx(int tile, const Geometry& g)
 struct FwdShared {
     float4 rec[B][3];
     unsigned long long mask[4 * B]; // [wave][entry]
+    int4 alive;                     // per wave: does it still have a live pixel (block_any_alive)
 };
+
+// "Does any wave of the workgroup still have a live pixel?"  The answer of a wave is already uniform (its alive mask
+// sits in scalar registers), so one lane posts it and everybody reads the four flags after the barrier --
+// __syncthreads_or would first reduce the flag over the 64 lanes with eight DPP steps.  The flags are rewritten only
+// behind the next batch's staging barrier.
+__device__ __forceinline__ bool block_any_alive(int4* flags, int w, int lane, unsigned long long alive_mask)
+{
+    if (lane == 0) reinterpret_cast<int*>(flags)[w] = alive_mask != 0ull ? 1 : 0;
+    __syncthreads();
+    const int4 f = *flags;
+    return ((f.x | f.y) | (f.z | f.w)) != 0;
+}
 
 // One tile's forward walk (main.cpp:419-536 for its pixels): leaves the final colour of this thread's pixel in
 // (crg, cb) and the lane masks of every staged pair in wave_masks.
@@ -256,7 +269,7 @@ __device__ __forceinline__ void forward_tile(FwdShared& s, const TileCtx& c, con
                 if (COUNT) n_act += (act >> lane) & 1ull;
             }
         }
-        if (!__syncthreads_or(alive_mask != 0ull ? 1 : 0)) break; // every pixel of the tile saturated: retire it
+        if (!block_any_alive(&s.alive, w, lane, alive_mask)) break; // every pixel of the tile saturated: retire it
     }
     if (COUNT) {
         atomicAdd(&counters->fwd_visited, n_vis);
@@ -421,6 +434,7 @@ struct BwdShared {
     float4 part[DET ? 4 : 1][B][3];
     unsigned long long touched[4]; // bit e: wave w wrote slot e in this batch
     double red[4];
+    int4 alive;                    // per wave: does it still have a live pixel (block_any_alive)
     __attribute__((aligned(16))) float xpose[4][kRedDwords]; // wave-private transpose scratch
 };
 
@@ -581,7 +595,7 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
             }
         }
         if (DET && lane == 0) s.touched[w] = touched;
-        const int any = __syncthreads_or(alive_mask != 0ull ? 1 : 0);
+        const bool any = block_any_alive(&s.alive, w, lane, alive_mask);
         // one burst per (tile, splat): 9 consecutive floats -- float atomics into grads[idx], or (deterministic
         // mode) plain stores into this tile's own slot of the splat, summed later in a fixed order
         for (int i = tid; i < cnt * 9; i += 256) {
@@ -689,7 +703,7 @@ __global__ __launch_bounds__(256) void raster_fused_kernel(const uint32_t* __res
     } else {
         fin = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    // (the forward walk ended with a workgroup barrier behind its last LDS read, or never touched LDS)
+    __syncthreads(); // the backward walk re-uses the LDS the forward walk's last flag exchange may still be reading
     backward_tile<false, NEED_OP, DET, EXACT>(*reinterpret_cast<BwdShared<DET>*>(smem), c, fin, ref, tile_off, list, proj,
                                               wave_masks, grads, tile_sqerr, g, det, nullptr);
 }
