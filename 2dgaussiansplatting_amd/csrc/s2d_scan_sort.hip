@@ -167,6 +167,9 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
 {
     __shared__ uint32_t s_cnt[4 * 256]; // per-wave running digit counts, then per-wave exclusive bases
     __shared__ uint32_t s_gbase[256];   // global start of (digit, this block)
+    __shared__ uint32_t s_boff[256];    // start of the digit's run in the block's sorted order
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_key[kSortItemsPerBlock], s_val[kSortItemsPerBlock];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < 4 * 256; i += kSortBlock) s_cnt[i] = 0;
@@ -200,7 +203,8 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
         rank[j] = prior + before;
     }
     __syncthreads();
-    // per digit: exclusive prefix over the 4 waves
+    // per digit: exclusive prefix over the 4 waves, and the block's total
+    uint32_t digit_total;
     {
         uint32_t run = 0;
 #pragma unroll
@@ -209,17 +213,35 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
             s_cnt[ww * 256 + tid] = run;
             run += t;
         }
+        digit_total = run;
+    }
+    // where each digit's run starts inside the block's sorted order
+    {
+        uint32_t unused;
+        s_boff[tid] = block_exclusive_scan_u32(digit_total, &unused, s_wave);
     }
     __syncthreads();
+    // Sort the block's items in LDS first (stable: rank order is memory order), then write them out in sorted order:
+    // consecutive threads then store consecutive words of a digit's run instead of 64 unrelated words per instruction.
 #pragma unroll
     for (int j = 0; j < kSortItemsPerThread; j++) {
         const int64_t i = wave_base + (int64_t)j * 64 + lane;
         if (i < n) {
             const uint32_t digit = (key[j] >> shift) & 255u;
-            const uint32_t dest = s_gbase[digit] + s_cnt[w * 256 + digit] + rank[j];
-            keys_out[dest] = key[j];
-            vals_out[dest] = val[j];
+            const uint32_t p = s_boff[digit] + s_cnt[w * 256 + digit] + rank[j];
+            s_key[p] = key[j];
+            s_val[p] = val[j];
         }
+    }
+    __syncthreads();
+    const int64_t block_base = (int64_t)blockIdx.x * kSortItemsPerBlock;
+    const uint32_t count = (uint32_t)min((int64_t)kSortItemsPerBlock, n - block_base);
+    for (uint32_t p = tid; p < count; p += kSortBlock) {
+        const uint32_t k = s_key[p];
+        const uint32_t digit = (k >> shift) & 255u;
+        const uint32_t dest = s_gbase[digit] + (p - s_boff[digit]);
+        keys_out[dest] = k;
+        vals_out[dest] = s_val[p];
     }
 }
 
