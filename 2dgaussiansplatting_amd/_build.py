@@ -63,7 +63,7 @@ def build_host_program(force=False, verbose=False):
         # rccl.h pulls in the HIP runtime API header: plain C declarations, fine for g++ (no device code in the host)
         cmd = ["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
                "-I", os.path.join(rocm, "include"), "-o", TRAIN_BIN, src,
-               "-L", LIB_DIR, "-lsplat2d_hip", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lz", "-lpthread",
+               "-L", LIB_DIR, "-lsplat2d_hip", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-lz", "-lpthread",
                "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
         if verbose:
             print(" ".join(cmd))

@@ -56,6 +56,8 @@ struct Options {
     int device = 0;
     int rebin_interval = 0;
     int gpus = 1;               // --gpus N: devices device .. device + N - 1, one row slab each, RCCL all-reduce of the gradients
+    bool share_gpu = false;     // --share-gpu: all N ranks on --device, gradients summed through host memory instead of RCCL
+                                // (RCCL takes one rank per GPU): a rehearsal of the N-rank host logic on a box with fewer GPUs
 };
 
 // Checkpoint = the state main() keeps between frames (main.cpp:272-278), in the reference's own layouts.
@@ -74,7 +76,7 @@ int usage()
                  "                     [--overlay file [--overlay-scale S] [--overlay-stride K]]\n"
                  "       splat2d_train --convert in.(s2di|ppm|png|jpg) out.(s2di|ppm|png)\n"
                  "                     [--load-checkpoint file] [--save-checkpoint file]\n"
-                 "                     [--device D] [--gpus N] [--rebin-interval R] [--quiet]\n");
+                 "                     [--device D] [--gpus N [--share-gpu]] [--rebin-interval R] [--quiet]\n");
     return 2;
 }
 
@@ -103,42 +105,80 @@ struct Barrier {
     std::mutex m;
     std::condition_variable cv;
     int n, waiting = 0, generation = 0;
+    bool broken = false; // a rank failed: nobody waits for it any more
     explicit Barrier(int n_) : n(n_) {}
     void wait()
     {
         std::unique_lock<std::mutex> lk(m);
+        if (broken) return;
         const int gen = generation;
         if (++waiting == n) {
             waiting = 0;
             generation++;
             cv.notify_all();
         } else {
-            cv.wait(lk, [&] { return gen != generation; });
+            cv.wait(lk, [&] { return gen != generation || broken; });
         }
+    }
+    void abort()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        broken = true;
+        cv.notify_all();
     }
 };
 
 struct MultiShared {
     Barrier barrier;
+    std::vector<float*> host_grads;         // --share-gpu: pinned host copies of the ranks' partial gradients; [0] receives the sum
     std::vector<std::vector<double>> sqerr; // [rank][iteration in batch]: partial squared errors (not yet normalised)
     std::atomic<int> failed{0};             // first failing status (any rank): everyone stops at the next barrier
     std::string error;
     std::mutex err_mutex;
-    explicit MultiShared(int world) : barrier(world), sqerr((size_t)world) {}
+    explicit MultiShared(int world) : barrier(world), host_grads((size_t)world, nullptr), sqerr((size_t)world) {}
 };
+
+// --share-gpu: the sum RCCL would form, through host memory.  Every rank copies its partial gradients out, rank 0 adds
+// them in rank order, every rank copies the sum back in.  Same result on every rank, like an all-reduce.
+bool staged_all_reduce(MultiShared& sh, int rank, int world, float* grads, size_t count, hipStream_t stream)
+{
+    bool ok = hipMemcpyAsync(sh.host_grads[(size_t)rank], grads, count * sizeof(float), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+              hipStreamSynchronize(stream) == hipSuccess;
+    sh.barrier.wait();
+    if (rank == 0)
+        for (int q = 1; q < world; q++) {
+            const float* src = sh.host_grads[(size_t)q];
+            float* dst = sh.host_grads[0];
+            for (size_t k = 0; k < count; k++) dst[k] += src[k];
+        }
+    sh.barrier.wait();
+    ok = ok && hipMemcpyAsync(grads, sh.host_grads[0], count * sizeof(float), hipMemcpyHostToDevice, stream) == hipSuccess &&
+         hipStreamSynchronize(stream) == hipSuccess;
+    sh.barrier.wait(); // nobody overwrites its host copy before everybody has read the sum
+    return ok;
+}
 
 int run_multi(const Options& o, int W, int H, const std::vector<float>& imageRef)
 {
     const int world = o.gpus;
     std::vector<int> devs((size_t)world);
-    for (int r = 0; r < world; r++) devs[(size_t)r] = o.device + r;
-    std::vector<ncclComm_t> comms((size_t)world);
-    ncclResult_t nrc = ncclCommInitAll(comms.data(), world, devs.data());
-    if (nrc != ncclSuccess) {
-        std::fprintf(stderr, "ncclCommInitAll(%d devices from %d): %s\n", world, o.device, ncclGetErrorString(nrc));
-        return 1;
-    }
+    for (int r = 0; r < world; r++) devs[(size_t)r] = o.share_gpu ? o.device : o.device + r;
+    std::vector<ncclComm_t> comms((size_t)world, nullptr);
+    ncclResult_t nrc = ncclSuccess;
     MultiShared sh(world);
+    if (!o.share_gpu) {
+        nrc = ncclCommInitAll(comms.data(), world, devs.data());
+        if (nrc != ncclSuccess) {
+            std::fprintf(stderr, "ncclCommInitAll(%d devices from %d): %s\n", world, o.device, ncclGetErrorString(nrc));
+            return 1;
+        }
+    } else {
+        for (int r = 0; r < world; r++)
+            if (hipHostMalloc((void**)&sh.host_grads[(size_t)r], (size_t)o.n_splats * 9 * sizeof(float) + 16, hipHostMallocDefault) != hipSuccess) {
+                std::fprintf(stderr, "--share-gpu: cannot allocate the host staging buffers\n");
+                return 1;
+            }
+    }
     std::vector<s2d_splat> final_splats;
     const auto t0 = std::chrono::steady_clock::now();
     auto rank_main = [&](int rank) {
@@ -147,6 +187,7 @@ int run_multi(const Options& o, int W, int H, const std::vector<float>& imageRef
             std::lock_guard<std::mutex> lk(sh.err_mutex);
             if (!sh.failed.exchange(rc == S2D_E_NONFINITE ? 3 : 1))
                 sh.error = std::string(what) + " on rank " + std::to_string(rank) + ": " + (ctx ? s2d_last_error(ctx) : "no context");
+            sh.barrier.abort(); // the other ranks stop at their next barrier instead of waiting for this one
         };
         s2d_config cfg;
         std::memset(&cfg, 0, sizeof(cfg));
@@ -172,13 +213,17 @@ int run_multi(const Options& o, int W, int H, const std::vector<float>& imageRef
         while (iterations < o.iters && !sh.failed.load()) {
             int k = o.batch;
             if (k > o.iters - iterations) k = o.iters - iterations;
-            for (int j = 0; j < k && rc == S2D_OK; j++) { // one frame of main.cpp:334, this rank's rows
+            for (int j = 0; j < k && rc == S2D_OK && !sh.failed.load(); j++) { // one frame of main.cpp:334, this rank's rows
                 rc = s2d_forward_backward(ctx, bwd_flags);
                 if (rc == S2D_OK) {
                     // the only exchange of the iteration: sum of the slabs' partial gradients, in place, on the stream the
                     // kernels run on (RCCL over xGMI)
-                    nrc = ncclAllReduce(grads, grads, (size_t)o.n_splats * 9, ncclFloat, ncclSum, comms[(size_t)rank], (hipStream_t)stream);
-                    if (nrc != ncclSuccess) rc = S2D_E_HIP;
+                    if (!o.share_gpu) {
+                        nrc = ncclAllReduce(grads, grads, (size_t)o.n_splats * 9, ncclFloat, ncclSum, comms[(size_t)rank], (hipStream_t)stream);
+                        if (nrc != ncclSuccess) rc = S2D_E_HIP;
+                    } else if (!staged_all_reduce(sh, rank, world, grads, (size_t)o.n_splats * 9, (hipStream_t)stream)) {
+                        rc = S2D_E_HIP;
+                    }
                 }
                 if (rc == S2D_OK) rc = s2d_adam_step(ctx, step_flags);
             }
@@ -204,14 +249,18 @@ int run_multi(const Options& o, int W, int H, const std::vector<float>& imageRef
     std::vector<std::thread> threads;
     for (int r = 0; r < world; r++) threads.emplace_back(rank_main, r);
     for (auto& t : threads) t.join();
-    for (auto& c : comms) ncclCommDestroy(c);
+    for (auto& c : comms)
+        if (c) ncclCommDestroy(c);
+    for (float* p : sh.host_grads)
+        if (p) (void)hipHostFree(p);
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (sh.failed.load()) {
         std::fprintf(stderr, "%s\n", sh.error.c_str());
         return sh.failed.load();
     }
-    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats, %d GPUs: row slabs + RCCL all-reduce of the gradients; "
-                         "includes context set-up)\n", o.iters, secs, secs > 0 ? o.iters / secs : 0.0, W, H, o.n_splats, world);
+    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats, %d ranks: row slabs + %s of the gradients; "
+                         "includes context set-up)\n", o.iters, secs, secs > 0 ? o.iters / secs : 0.0, W, H, o.n_splats, world,
+                 o.share_gpu ? "host-staged sum (ranks share one GPU)" : "RCCL all-reduce");
     return 0;
 }
 
@@ -243,6 +292,7 @@ int main(int argc, char** argv)
         else if (a == "--save-checkpoint") o.save_ckpt = next("--save-checkpoint");
         else if (a == "--device") o.device = std::atoi(next("--device"));
         else if (a == "--gpus") o.gpus = std::atoi(next("--gpus"));
+        else if (a == "--share-gpu") o.share_gpu = true;
         else if (a == "--rebin-interval") o.rebin_interval = std::atoi(next("--rebin-interval"));
         else if (a == "--quiet") o.quiet = true;
         else return usage();

@@ -1088,3 +1088,21 @@ def test_forward_backward_skip_image_flag():
     t.forward_backward(skip_image=True)           # a step later: the old frame stays
     assert t.get_image().tobytes() == old.tobytes()
     t.close(); t2.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_cpp_host_n_ranks_sharing_the_gpu(world):
+    """splat2d_train --gpus N --share-gpu: the N-rank host logic of the C++ loop (one thread + one slab context per rank,
+    gradient sum between s2d_forward_backward and s2d_adam_step, host-side sum of the slabs' squared errors) on a box
+    with one GPU -- the sum goes through host memory because RCCL takes one rank per GPU.  The trace must follow the
+    single-context one (only the fp32 order of the gradient sums differs)."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(S2D.__file__), "lib", "splat2d_train")
+    args = [exe, "--image", MINI, "--splats", "1024", "--iters", "12", "--batch", "3"]
+    want = subprocess.run(args, capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    p = subprocess.run(args + ["--gpus", str(world), "--share-gpu"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = [ln for ln in p.stdout.strip().splitlines() if " itr, mse " in ln]
+    assert len(got) == 12 and got[0] == "0 itr, mse 5934.9042"
+    np.testing.assert_allclose([float(l.split("mse")[1]) for l in got], [float(l.split("mse")[1]) for l in want], rtol=2e-5)
+    assert "%d ranks" % world in p.stderr
