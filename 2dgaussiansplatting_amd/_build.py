@@ -25,6 +25,22 @@ HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off"
                "-Wall", "-Wno-unused-function"]
 
 
+def kernel_source_digest():
+    """sha256[:16] over the device sources with comments and whitespace removed: what ties a recorded profile
+    (profiles/traffic.json) to the kernels it measured (bench.py drops the figure when the digests differ)."""
+    import hashlib
+    import re
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h", ".inc")):
+            text = open(os.path.join(CSRC, name)).read()
+            text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+            text = re.sub(r"//[^\n]*", "", text)
+            h.update(name.encode())
+            h.update(re.sub(r"\s+", "", text).encode())
+    return h.hexdigest()[:16]
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

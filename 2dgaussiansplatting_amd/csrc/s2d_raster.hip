@@ -2,26 +2,32 @@
 //
 // One 256-thread workgroup (4 wave64) per 16x16 image tile, one thread per pixel.  Each wave owns an 8x8 pixel
 // block of the tile, lane = 8 * (row in block) + (column in block).  A tile walks its splat list (ascending splat index ==
-// the reference's blend order, main.cpp:419/:552) in batches of 64 entries staged in LDS:
-//   * 4 threads per entry load the 64-byte projected record and evaluate the reference's exact per-row
+// the reference's blend order, main.cpp:419/:552) twice -- forward_tile, then backward_tile -- in batches of 64 entries
+// staged in LDS:
+//   * forward walk: 4 threads per entry load the 64-byte projected record and evaluate the reference's exact per-row
 //     column range (solve_quadratic + int truncation, main.cpp:498-509) for 4 tile rows each, producing one
 //     64-bit lane mask per (entry, wave): bit l set <=> the reference's loops visit that pixel for that
-//     splat.  The quadratic is solved once per (entry, row), not per pixel.
-//     The forward kernel also stores these masks (32 B per staged pair); the backward kernel of the same
-//     iteration, which walks exactly the same batches, loads them instead of solving the quadratics again.
-//   * after the barrier lane l of every wave fetches the mask of entry l; a ballot of "mask != 0" is the
-//     set of entries that touch this wave at all, and the blend loop iterates over its set bits only
-//     (scalar bit tricks + v_readlane), skipping an entry with a scalar branch when no LIVE lane is covered.
+//     splat.  The quadratic is solved once per (entry, row), not per pixel.  The masks are also stored (32 B per
+//     staged pair); the backward walk, which goes through exactly the same batches, loads them instead of solving
+//     the quadratics again.
+//   * after the barrier lane l of every wave fetches the mask of entry l; a ballot of "mask touches a live pixel" is
+//     the set of entries this wave has to look at, and the blend loop iterates over its set bits only
+//     (scalar bit tricks + v_readlane), skipping an entry with a scalar branch when no lane is live any more.
 // A pixel whose throughput fell below 1/256 never works again (main.cpp:520); when all 256 pixels of the tile
 // are in that state the workgroup stops walking its list (tile retirement).
 //
+// Kernels: raster_fused_kernel runs both walks of a tile in one launch, the final colours staying in registers
+// (what s2d_step and s2d_forward_backward queue); raster_forward_kernel / raster_backward_kernel run one walk each
+// through image0 (s2d_forward / s2d_backward, and the counting diagnostics).
+//
 // The alpha / throughput / colour arithmetic is the reference's, operation for operation
-// (-ffp-contract=off), in both kernels, so the framebuffer is bit-identical to the oracle's and the backward
-// pass makes exactly the forward's per-pixel decisions.  The backward pass then reduces each splat's nine
-// partial gradients over the wave with DPP, over the four waves through per-wave LDS slots (plain stores,
-// fixed order), and issues one global float-atomic burst per (tile, splat) into the N x 9 gradient array -- or,
-// with S2D_CFG_DETERMINISTIC, stores the partial into the tile's own slot of that splat, and a gather kernel
-// sums each splat's slots in a fixed order (bitwise reproducible gradients).
+// (-ffp-contract=off), in both walks, so the framebuffer is bit-identical to the oracle's and the backward
+// walk makes exactly the forward's per-pixel decisions.  The backward walk then sums each splat's nine
+// partial gradients over the wave through an LDS transpose (wave_sum8_lds), over the four waves in one LDS slot per
+// entry, and issues one global float-atomic burst per (tile, splat) into the N x 9 gradient array -- or,
+// with S2D_CFG_DETERMINISTIC, keeps one slot per wave, adds them in a fixed order and stores the partial into the
+// tile's own slot of that splat, and a gather kernel sums each splat's slots in a fixed order (bitwise
+// reproducible gradients).
 #include <hip/hip_fp16.h>
 
 #include "s2d_device.h"

@@ -83,15 +83,8 @@ def cpu_baseline(W, H, n, threads):
 
 
 def kernel_source_digest():
-    """sha256[:16] over the kernel sources: ties a recorded profile (profiles/traffic.json) to the build it measured."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "2dgaussiansplatting_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h", ".inc")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
-    return h.hexdigest()[:16]
+    """Ties a recorded profile (profiles/traffic.json) to the kernels it measured: comments and whitespace do not count."""
+    return importlib.import_module("2dgaussiansplatting_amd._build").kernel_source_digest()
 
 
 def spawn_ranks(n, argv):

@@ -70,20 +70,17 @@ def main():
                                                        sum(work) / len(work), statistics.median(work)))
         print("wrote", sys.argv[3])
     elif mode == "traffic":
-        import hashlib, json
+        import json
         rows = [r for r in csv.reader(l for l in open(sys.argv[2]) if not l.startswith("#"))]
         hdr, rows = rows[0], rows[1:]
         ifetch, iwrite = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE")
         cand = [r for r in rows if "raster_fused_kernel<false; false; false; false>" in r[0]] or [r for r in rows if "raster_" in r[0]]
         r = max(cand, key=lambda r: int(r[1]))
         fetch_kb, write_kb = float(r[ifetch]), float(r[iwrite])
+        import importlib
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-        d = os.path.join(root, "2dgaussiansplatting_amd", "csrc")
-        h = hashlib.sha256()
-        for name in sorted(os.listdir(d)):
-            if name.endswith((".hip", ".h", ".inc")):
-                h.update(name.encode())
-                h.update(open(os.path.join(d, name), "rb").read())
+        sys.path.insert(0, root)
+        digest = importlib.import_module("2dgaussiansplatting_amd._build").kernel_source_digest()
         out = {
             "source": "%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes; tools/gpu_profile_round.sh)" % os.path.basename(sys.argv[2]),
             "workload": "4096x4096 synthetic, 1,000,000 Gaussians, 1 GPU (python3 bench.py)",
@@ -94,7 +91,7 @@ def main():
                           "this kernel also makes 8-B mask accesses and 64-B record gathers, widths the guide calls uncalibrated, so the "
                           "figure is an upper estimate",
             "dominant_kernel_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
-            "kernel_source_digest": h.hexdigest()[:16],
+            "kernel_source_digest": digest,
         }
         json.dump(out, open(sys.argv[3], "w"), indent=1)
         print("wrote", sys.argv[3])
