@@ -70,39 +70,38 @@ typedef enum s2d_status {
 /* s2d_step / s2d_adam_step flags */
 #define S2D_STEP_OPTIMIZE_OPACITY 0x1u /* the "Optimize opacity" checkbox, main.cpp:317, :735-738, :825 */
 
-#define S2D_CFG_DETERMINISTIC 0x4u /* bitwise reproducible gradients: tiles store their per-splat partial sums into
-                                   * private slots and a gather pass adds them in a fixed order, instead of float
-                                   * atomics whose arrival order varies from run to run (the forward pass is
-                                   * deterministic either way).  Costs a few per cent. */
-
-/* s2d_backward flags */
+/* s2d_backward / s2d_forward_backward flags */
 #define S2D_BWD_SKIP_OPACITY_GRAD 0x1u /* leave dSplats.opacity at zero.  The reference always accumulates it
                                         * (main.cpp:704) but reads it only when "Optimize opacity" is on (main.cpp:735):
                                         * a caller whose next s2d_adam_step runs without S2D_STEP_OPTIMIZE_OPACITY
                                         * may skip it.  s2d_step does so by itself. */
+#define S2D_FB_SKIP_IMAGE 0x2u         /* s2d_forward_backward only: do not store image0 (the backward walk takes the final
+                                        * colours from registers); s2d_get_image then returns an older frame.  For training
+                                        * loops that never look at it. */
 
 /* s2d_config.flags */
-#define S2D_CFG_COUNT_PAIRS 0x1u /* count visited / active pixel-splat pairs in the raster kernels (diagnostic) */
-#define S2D_CFG_FP16_IMAGES 0x2u /* BASELINE configs[4] "fp16 color / fp32 grads": the framebuffer and the target are
-                                  * held in HBM as 4 x fp16 per pixel (round to nearest even); all arithmetic, the
-                                  * gradients and the optimiser stay fp32.  Images still cross this ABI as RGBA32F.
-                                  * Not the reference's arithmetic: results equal the reference run with imageRef and
-                                  * image0 rounded to fp16 (tests/test_gpu_parity.py::test_fp16_images_*). */
-
-#define S2D_CFG_EXACT_EXP 0x8u   /* validation mode: exp_approx returns expf(x), the switch the reference keeps at
-                                  * main.cpp:51 "for numerical varidation".  The analytic gradients (main.cpp:639-704) are
-                                  * those of the true exponential, so in this mode the backward pass is the derivative of
-                                  * the forward pass and a finite-difference check closes (tests/test_gpu_fd.py).  Not
-                                  * combinable with S2D_CFG_COUNT_PAIRS / S2D_CFG_FP16_IMAGES. */
-
-#define S2D_CFG_ADAM_FP32 0x10u  /* Adam::optimize (main.cpp:155) with the quotient and subtraction in fp32, as the
-                                  * reference's own MSVC build evaluates the unqualified `sqrt` (float overload).  Default:
-                                  * the double-precision quotient of a g++/clang++ build, which is what the known-answer
-                                  * vectors pin.  The two differ by <= 1 ulp of the parameter
-                                  * + ~3 ulp of the update per step; 100-iteration traces by a few 1e-4 (test_oracle_kat.py). */
-
-#define S2D_FB_SKIP_IMAGE 0x2u /* s2d_forward_backward only: do not store image0 (the backward walk takes the final colours from
-                                * registers); s2d_get_image then returns an older frame.  For training loops that never look. */
+#define S2D_CFG_COUNT_PAIRS 0x1u   /* count visited / active pixel-splat pairs in the raster kernels (diagnostic) */
+#define S2D_CFG_FP16_IMAGES 0x2u   /* BASELINE configs[4] "fp16 color / fp32 grads": the framebuffer and the target are
+                                    * held in HBM as 4 x fp16 per pixel (round to nearest even); all arithmetic, the
+                                    * gradients and the optimiser stay fp32.  Images still cross this ABI as RGBA32F.
+                                    * Not the reference's arithmetic: results equal the reference run with imageRef and
+                                    * image0 rounded to fp16 (tests/test_gpu_parity.py::test_fp16_images_*). */
+#define S2D_CFG_DETERMINISTIC 0x4u /* bitwise reproducible gradients: tiles store their per-splat partial sums into
+                                    * private slots and a gather pass adds them in a fixed order, instead of float
+                                    * atomics whose arrival order varies from run to run (the forward pass is
+                                    * deterministic either way).  About a quarter slower at 4096^2 / 10^6 splats. */
+#define S2D_CFG_EXACT_EXP 0x8u     /* validation mode: exp_approx returns expf(x), the switch the reference keeps at
+                                    * main.cpp:51 "for numerical varidation".  The analytic gradients (main.cpp:639-704)
+                                    * are those of the true exponential, so in this mode the backward pass is the
+                                    * derivative of the forward pass and a finite-difference check closes
+                                    * (tests/test_fd_end_to_end.py).  Not combinable with S2D_CFG_COUNT_PAIRS /
+                                    * S2D_CFG_FP16_IMAGES. */
+#define S2D_CFG_ADAM_FP32 0x10u    /* Adam::optimize (main.cpp:155) with the quotient and subtraction in fp32, as the
+                                    * reference's own MSVC build evaluates the unqualified `sqrt` (float overload).
+                                    * Default: the double-precision quotient of a g++/clang++ build, which is what the
+                                    * known-answer vectors pin.  The two differ by <= 1 ulp
+                                    * of the parameter + ~3 ulp of the update per step; 100-iteration MSE traces by 2e-5
+                                    * (tests/test_oracle_kat.py). */
 
 typedef struct s2d_config {
     uint32_t struct_size;   /* = sizeof(s2d_config) */
