@@ -352,6 +352,7 @@ def main():
             flops = 30.0 * cs["fwd_active"] + 110.0 * cs["bwd_active"]
             out["compute"] = {"unit": "TFLOP/s", "achieved": flops * its / 1e12, "peak": 157.3,
                               "frac": flops * its / 1e12 / 157.3, "active_pairs_per_pass": cs["bwd_active"],
+                              "visited_pairs_per_pass": cs["bwd_visited"], "staged_list_entries_per_pass": cs["bwd_staged"],
                               "lanes_per_executed_wave_entry": cs["bwd_active"] / max(cs["bwd_wave_execs"], 1),
                               "executed_wave_entries_per_pass": cs["bwd_wave_execs"],
                               "note": "useful fp32 VALU flops only; kernels are VALU-issue-bound (DESIGN.md section 4)"}
