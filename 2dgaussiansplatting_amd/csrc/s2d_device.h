@@ -53,6 +53,15 @@ struct DeviceStatus {
     int pad;
 };
 
+// A squared-error reduction riding on another launch (tile_sqerr == nullptr: none): the Adam launch's first
+// workgroups (large images), or the raster launch's last tile (images of at most kSqerrSmallTiles tiles).
+struct SqerrJob {
+    const double* tile_sqerr;
+    int num_tiles;
+    double* out;
+    double* scratch;
+};
+
 #if defined(__HIPCC__)
 __device__ __forceinline__ float as_f(int v) { return __int_as_float(v); }
 
@@ -177,7 +186,7 @@ hipError_t launch_raster_fused(const uint32_t* tile_off, const uint32_t* list, c
                                const void* image_ref, bool half_images, unsigned long long* wave_masks, float* grads,
                                double* tile_sqerr, Geometry g, bool need_opacity_grad, const DetGather* dg,
                                const DeviceStatus* status, int abort_stamp, int iteration, bool write_image, bool exact_exp,
-                               hipStream_t stream);
+                               SqerrJob sq, hipStream_t stream);
 // Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
 // slab ownership (s2d_halo.hip): `held` == nullptr means every splat is held (single rank, or replicated state)
 hipError_t launch_halo_masks(const float* splats, const uint8_t* held, int n, int world, const int* row_bounds, float margin,
@@ -192,6 +201,8 @@ hipError_t launch_grads_combine(float* grads, const int* rows, int n_rows, const
 // scratch: kSqerrScratchDoubles doubles, zero before the first launch
 constexpr int kSqerrChunks = 64;
 constexpr int kSqerrScratchDoubles = kSqerrChunks + 1;
+constexpr int kSqerrSmallTiles = 1024; // up to here ONE workgroup adds the tile errors in one pass (sqerr_sum_small)
+
 
 #if defined(__HIPCC__)
 __device__ __forceinline__ double block_sum_256(double v, double* s)
@@ -205,6 +216,17 @@ __device__ __forceinline__ double block_sum_256(double v, double* s)
     return r;
 }
 
+// Small images: the whole sum by the calling workgroup, one pass, one fixed order (thread t adds tiles t, t + 256,
+// t + 512, t + 768, then the block sum).  Every path that sums a small image's tile errors uses this, so the MSE does
+// not depend on the path.  The tile errors were written by other workgroups: agent-scope loads.
+__device__ __forceinline__ double sqerr_sum_small(const double* tile_sqerr, int num_tiles, double* s4)
+{
+    double a = 0.0;
+    for (int i = (int)threadIdx.x; i < num_tiles; i += 256)
+        a += __hip_atomic_load(tile_sqerr + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return block_sum_256(a, s4);
+}
+
 // Sum of the per-tile squared errors in a FIXED order (a deterministic MSE trace, main.cpp:796-805), shared between
 // workgroups: the tiles are cut into kSqerrChunks contiguous chunks; the calling 256-thread workgroup reduces chunks
 // first_chunk, first_chunk + chunk_stride, ... into scratch[chunk]; the workgroup that completes the last chunk (a
@@ -216,6 +238,12 @@ __device__ __forceinline__ void sqerr_reduce(const double* __restrict__ tile_sqe
 {
     __shared__ double s[4];
     __shared__ bool last;
+    if (num_tiles <= kSqerrSmallTiles) { // one workgroup does it all (the one that was handed chunk 0)
+        if (first_chunk != 0) return;
+        const double total = sqerr_sum_small(tile_sqerr, num_tiles, s);
+        if (threadIdx.x == 0) *out = total;
+        return;
+    }
     unsigned long long* ticket = reinterpret_cast<unsigned long long*>(scratch + kSqerrChunks);
     const int chunk = (num_tiles + kSqerrChunks - 1) / kSqerrChunks;
     unsigned long long mine = 0;
@@ -255,14 +283,6 @@ hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double
 hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream);
 // proj != nullptr: also project the UPDATED splat for the next iteration and check it against rects[]
 // (what project_kernel mode 1 would do), raising status->rebin_needed.
-// sq.tile_sqerr != nullptr: the launch's first workgroups also reduce the per-tile squared errors of the backward pass
-// queued before it into *sq.out (sqerr_reduce), which saves the separate finalize dispatch.
-struct SqerrJob {
-    const double* tile_sqerr;
-    int num_tiles;
-    double* out;
-    double* scratch;
-};
 hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t* held_ids, const uint32_t* held_count, int n,
                        Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,

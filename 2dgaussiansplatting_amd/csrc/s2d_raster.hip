@@ -441,6 +441,7 @@ struct BwdShared {
     unsigned long long touched[4]; // bit e: wave w wrote slot e in this batch
     double red[4];
     int4 alive;                    // per wave: does it still have a live pixel (block_any_alive)
+    int last_tile;                 // this workgroup stored the launch's last tile error: it adds them all up
     __attribute__((aligned(16))) float xpose[4][kRedDwords]; // wave-private transpose scratch
 };
 
@@ -452,7 +453,8 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
                                               const ProjRec* __restrict__ proj,
                                               const unsigned long long* __restrict__ wave_masks,
                                               float* __restrict__ grads, double* __restrict__ tile_sqerr,
-                                              const Geometry& g, const DetSlots& det, PairCounters* __restrict__ counters)
+                                              const Geometry& g, const DetSlots& det, PairCounters* __restrict__ counters,
+                                              const SqerrJob& sq)
 {
     const int tid = c.tid, lane = c.lane, w = c.w;
     const bool inside = c.inside;
@@ -472,7 +474,28 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
     if (!DET)
         for (int i = tid; i < B * 3; i += 256) s.part[0][i / 3][i % 3] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
-    if (tid == 0) tile_sqerr[c.tile] = ((s.red[0] + s.red[1]) + s.red[2]) + s.red[3];
+    if (sq.out == nullptr) {
+        if (tid == 0) tile_sqerr[c.tile] = ((s.red[0] + s.red[1]) + s.red[2]) + s.red[3];
+    } else {
+        // Small images: the iteration's squared error (main.cpp:796-805) is summed here, by the workgroup whose tile
+        // error completes the set (a ticket behind the stores), instead of by a launch of its own.
+        if (tid == 0) {
+            __hip_atomic_store(tile_sqerr + c.tile, ((s.red[0] + s.red[1]) + s.red[2]) + s.red[3], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+            unsigned long long* ticket = reinterpret_cast<unsigned long long*>(sq.scratch + kSqerrChunks);
+            s.last_tile = atomicAdd(ticket, 1ull) == (unsigned long long)(sq.num_tiles - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        if (s.last_tile) { // block-uniform
+            __threadfence();
+            const double total = sqerr_sum_small(tile_sqerr, sq.num_tiles, s.red);
+            if (tid == 0) {
+                *sq.out = total;
+                *reinterpret_cast<unsigned long long*>(sq.scratch + kSqerrChunks) = 0ull;
+            }
+        }
+    }
 
     f2 crg = mk2(0.0f, 0.0f);                        // image1 = (0,0,0,1), main.cpp:549
     float cb = 0.0f, T = 1.0f;
@@ -667,7 +690,8 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
         fin = load_pixel<HALF>(image0, (size_t)c.y * g.W + c.x);    // finalColor, main.cpp:613
         ref = load_pixel<HALF>(image_ref, (size_t)c.y * g.W + c.x);
     }
-    backward_tile<COUNT, NEED_OP, DET, EXACT>(s, c, fin, ref, tile_off, list, proj, wave_masks, grads, tile_sqerr, g, det, counters);
+    backward_tile<COUNT, NEED_OP, DET, EXACT>(s, c, fin, ref, tile_off, list, proj, wave_masks, grads, tile_sqerr, g, det, counters,
+                                              SqerrJob{nullptr, 0, nullptr, nullptr});
 }
 
 // Forward and backward walk of a tile in ONE launch (what s2d_step and s2d_forward_backward queue): a tile's backward
@@ -686,7 +710,7 @@ __global__ __launch_bounds__(256) void raster_fused_kernel(const uint32_t* __res
                                                            float* __restrict__ grads, double* __restrict__ tile_sqerr,
                                                            Geometry g, DetSlots det,
                                                            const DeviceStatus* __restrict__ status, int abort_stamp,
-                                                           int iteration, int write_image)
+                                                           int iteration, int write_image, SqerrJob sq)
 {
     constexpr size_t kBytes = sizeof(BwdShared<DET>) > sizeof(FwdShared) ? sizeof(BwdShared<DET>) : sizeof(FwdShared);
     __shared__ __attribute__((aligned(16))) unsigned char smem[kBytes]; // the two walks use the same LDS one after the other
@@ -711,7 +735,7 @@ __global__ __launch_bounds__(256) void raster_fused_kernel(const uint32_t* __res
     }
     __syncthreads(); // the backward walk re-uses the LDS the forward walk's last flag exchange may still be reading
     backward_tile<false, NEED_OP, DET, EXACT>(*reinterpret_cast<BwdShared<DET>*>(smem), c, fin, ref, tile_off, list, proj,
-                                              wave_masks, grads, tile_sqerr, g, det, nullptr);
+                                              wave_masks, grads, tile_sqerr, g, det, nullptr, sq);
 }
 
 // Deterministic mode: gradient of splat i = sum of the partials its tiles stored this iteration, in emission
@@ -812,7 +836,7 @@ hipError_t launch_raster_fused(const uint32_t* tile_off, const uint32_t* list, c
                                const void* image_ref, bool half_images, unsigned long long* wave_masks, float* grads,
                                double* tile_sqerr, Geometry g, bool need_opacity_grad, const DetGather* dg,
                                const DeviceStatus* status, int abort_stamp, int iteration, bool write_image, bool exact_exp,
-                               hipStream_t stream)
+                               SqerrJob sq, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
     DetSlots det{nullptr, nullptr, nullptr, nullptr, 0u};
@@ -821,7 +845,7 @@ hipError_t launch_raster_fused(const uint32_t* tile_off, const uint32_t* list, c
     const int wi = write_image ? 1 : 0;
 #define S2D_LAUNCH_FUSED(O, H, D, X)                                                                                       \
     hipLaunchKernelGGL((raster_fused_kernel<O, H, D, X>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
-                       wave_masks, grads, tile_sqerr, g, det, status, abort_stamp, iteration, wi)
+                       wave_masks, grads, tile_sqerr, g, det, status, abort_stamp, iteration, wi, sq)
 #define S2D_LAUNCH_FUSED_D(O, H, X) do { if (dg) S2D_LAUNCH_FUSED(O, H, true, X); else S2D_LAUNCH_FUSED(O, H, false, X); } while (0)
     if (exact_exp) {
         if (need_opacity_grad) S2D_LAUNCH_FUSED_D(true, false, true); else S2D_LAUNCH_FUSED_D(false, false, true);
