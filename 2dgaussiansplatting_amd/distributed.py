@@ -39,18 +39,42 @@ def slab_rows(height, rank, world, tile=16):
 
 class SlabStep:
     """One training iteration of one rank.  The collective and the backend must work on the same stream (bench.py
-    creates the Trainer on torch's current stream), or the caller must synchronise between them."""
+    creates the Trainer on torch's current stream), or the caller must synchronise between them.
 
-    def __init__(self, backend, grads, dist=None):
+    The replicas stay bit-identical only because every rank applies the same Adam step to the same all-reduced
+    gradients; `params` (a callable returning the rank's parameters as a tensor) + `check_interval` assert that every so
+    many iterations with a checksum exchanged over the same collective."""
+
+    def __init__(self, backend, grads, dist=None, params=None, check_interval=0):
         self.backend = backend
         self.grads = grads  # torch tensor aliasing the backend's gradient buffer (n * 9 fp32)
         self.dist = dist    # torch.distributed module, or None for a single process
+        self.params, self.check_interval, self.it, self.checks = params, int(check_interval), 0, 0
 
     def __call__(self, before_raster=None, after_raster=None):
         _raster(self.backend, before_raster, after_raster)
         if self.dist is not None:
             self.dist.all_reduce(self.grads)  # sum of the slabs' partial gradients, in place
         self.backend.adam_step()
+        self.it += 1
+        if self.dist is not None and self.params is not None and self.check_interval > 0 and self.it % self.check_interval == 0:
+            self.assert_replicas_identical()
+
+    def assert_replicas_identical(self):
+        """Every rank's parameters have the same bits: a 64-bit checksum of them (sum of the words, and of the words
+        times their position) must come back from a MIN and a MAX all-reduce unchanged."""
+        import torch
+        w = self.params().contiguous().view(torch.int32).flatten().to(torch.int64)
+        pos = torch.arange(1, w.numel() + 1, dtype=torch.int64, device=w.device)
+        mine = torch.stack([w.sum(), (w * (pos % 65521)).sum()])
+        lo, hi = mine.clone(), mine.clone()
+        if self.dist.get_backend() == "gloo" and lo.is_cuda:
+            lo, hi = lo.cpu(), hi.cpu()
+        self.dist.all_reduce(lo, op=self.dist.ReduceOp.MIN)
+        self.dist.all_reduce(hi, op=self.dist.ReduceOp.MAX)
+        self.checks += 1
+        if not bool((lo == hi).all()):
+            raise RuntimeError("row-slab replicas diverged: parameter checksums differ between ranks at iteration %d" % self.it)
 
 
 def reduce_sqerr(sqerr, dist=None):

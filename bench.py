@@ -203,7 +203,11 @@ def main():
         # forward, backward, exchange of the gradient rows of splats held by more than one rank, Adam on held splats
         step = D.HaloStep(t, D.HipHaloOps(t, n, "cuda"), dist, rank, world, H)
     else:
-        step = D.SlabStep(t, grads, dist)  # forward, backward, all-reduce(grads), Adam
+        # forward + backward, all-reduce(grads), Adam; every 64 iterations the replicas' parameter checksums are compared
+        ops = D.HipHaloOps(t, n, "cuda") if world > 1 else None
+        all_ids = torch.arange(n, dtype=torch.int32, device="cuda") if world > 1 else None
+        step = D.SlabStep(t, grads, dist, params=(lambda: ops.rows_gather(D.ROWS_SPLATS, all_ids)) if world > 1 else None,
+                          check_interval=64)
 
     def one_step(ev=None):
         if ev is None:
@@ -327,7 +331,8 @@ def main():
             "iterations_total": stats["iterations"],
             "exchange_rank0": ({"scheme": "halo", "held_fraction": float(((step.mask >> rank) & 1).float().mean().item()),
                                 "rows_exchanged_per_iteration": int(sum(step.splits)), "state_handovers": int(step.handed_over)}
-                               if isinstance(step, D.HaloStep) else {"scheme": "dense" if world > 1 else "none"}),
+                               if isinstance(step, D.HaloStep) else
+                               {"scheme": "dense" if world > 1 else "none", "replica_checksum_checks": getattr(step, "checks", 0)}),
             "pairs_binned_rank0": stats["pairs_binned"],
             "rebins_rank0": stats["rebins"],
             "roofline": {"bound": "hbm", "kernel": "raster_fused_kernel", "achieved": achieved, "peak": 8000.0,

@@ -60,9 +60,20 @@ def _worker(rank, world, port, steps, n, out):
         tgt = O.target_rgba32f(O.load_s2di(os.path.join(O.GOLDEN, "squirrel_cls_mini_268x213.s2di")))
         r0, r1 = D.slab_rows(tgt.shape[0], rank, world)
         be = OracleSlabBackend(tgt, n, r0, r1)
-        step = D.SlabStep(be, be.grads, dist)
+        step = D.SlabStep(be, be.grads, dist, params=lambda: torch.from_numpy(be.o.splats.view(np.float32).reshape(-1, 9)),
+                          check_interval=2)
         for _ in range(steps):
             step()
+        assert step.checks == steps // 2       # the replica checksum was exchanged and agreed
+        if rank == 1:                          # ... and a replica that drifts by one bit is caught (on every rank)
+            be.o.splats["pos"][0, 0] = np.nextafter(be.o.splats["pos"][0, 0], np.float32(1e9))
+        try:
+            step.assert_replicas_identical()
+            raise AssertionError("a diverged replica went unnoticed")
+        except RuntimeError:
+            pass
+        if rank == 1:
+            be.o.splats["pos"][0, 0] = np.nextafter(be.o.splats["pos"][0, 0], np.float32(-1e9))
         sq = D.reduce_sqerr(torch.tensor(be.sqerr, dtype=torch.float64), dist)
         gathered = [torch.zeros(n * 9) for _ in range(world)]
         dist.all_gather(gathered, torch.from_numpy(be.o.splats.view(np.float32).reshape(-1).copy()))
