@@ -26,13 +26,14 @@ HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off"
 
 
 def kernel_source_digest():
-    """sha256[:16] over the device sources with comments and whitespace removed: what ties a recorded profile
-    (profiles/traffic.json) to the kernels it measured (bench.py drops the figure when the digests differ)."""
+    """sha256[:16] over the sources of the raster kernels (s2d_raster.hip and the two headers it is made of) with
+    comments and whitespace removed: what ties a recorded profile of the dominant kernel (profiles/traffic.json) to the
+    code it measured (bench.py drops the figure when the digests differ)."""
     import hashlib
     import re
     h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)):
-        if name.endswith((".hip", ".h", ".inc")):
+    for name in ("s2d_device.h", "s2d_math.h", "s2d_raster.hip"):
+        if os.path.exists(os.path.join(CSRC, name)):
             text = open(os.path.join(CSRC, name)).read()
             text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
             text = re.sub(r"//[^\n]*", "", text)

@@ -80,6 +80,7 @@ struct s2d_ctx {
     // pinned host mirrors
     uint32_t* h_total = nullptr;
     DeviceStatus* h_status = nullptr;
+    double* h_trace = nullptr;          // kHostTrace squared errors: s2d_step reads its trace and the status word in ONE round trip
 
     // host-side state of the reference's main()
     float beta1t = 1.0f, beta2t = 1.0f; // main.cpp:274-275
@@ -95,6 +96,8 @@ struct s2d_ctx {
 };
 
 namespace {
+
+constexpr int kHostTrace = 4096;
 
 int fail(s2d_ctx* c, int code, const char* fmt, ...)
 {
@@ -373,10 +376,18 @@ int reset_status(s2d_ctx* c)
     return S2D_OK;
 }
 
+// The status word has been copied to h_status and the stream synchronised: act on it.
+int judge_status(s2d_ctx* c);
+
 int check_status(s2d_ctx* c)
 {
     S2D_HIP(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(DeviceStatus), hipMemcpyDeviceToHost, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
+    return judge_status(c);
+}
+
+int judge_status(s2d_ctx* c)
+{
     if (c->h_status->nonfinite) {
         // The kernels queued behind the failing Adam step did nothing: put the host-side counters back to where the
         // device stopped (that step's update is the last thing that happened, as at the reference's abort()).
@@ -472,6 +483,7 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, hipEventCreateWithFlags(&c->ev_flag, hipEventDisableTiming));
     S2D_HIP(c, hipHostMalloc((void**)&c->h_total, 64, hipHostMallocDefault));
     S2D_HIP(c, hipHostMalloc((void**)&c->h_status, sizeof(DeviceStatus), hipHostMallocDefault));
+    S2D_HIP(c, hipHostMalloc((void**)&c->h_trace, kHostTrace * sizeof(double), hipHostMallocDefault));
     S2D_HIP(c, hipHostMalloc((void**)&c->h_rebin_stamp, 64, hipHostMallocMapped));
     *c->h_rebin_stamp = 0;
 
@@ -506,6 +518,7 @@ void s2d_destroy(s2d_ctx* c)
         if (c->ev_flag) (void)hipEventDestroy(c->ev_flag);
         if (c->h_total) (void)hipHostFree(c->h_total);
         if (c->h_status) (void)hipHostFree(c->h_status);
+        if (c->h_trace) (void)hipHostFree(c->h_trace);
         if (c->h_rebin_stamp) (void)hipHostFree(c->h_rebin_stamp);
         if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     }
@@ -677,6 +690,7 @@ int s2d_step(s2d_ctx* c, int32_t iters, uint32_t flags, double* mse_out)
     const double norm = mse_norm(c);
     const int call_first_iter = c->iterations;
     int done = 0;
+    bool status_read = false;
     while (done < iters) {
         const int chunk = std::min(iters - done, c->trace_cap);
         const int first_iter = c->iterations;
@@ -686,13 +700,27 @@ int s2d_step(s2d_ctx* c, int32_t iters, uint32_t flags, double* mse_out)
             if (int rc = queue_forward_backward(c, (flags & S2D_STEP_OPTIMIZE_OPACITY) != 0, last, true)) return rc;
             if (int rc = queue_adam(c, flags)) return rc;
         }
-        if (mse_out) {
+        const bool last_chunk = done + chunk == iters;
+        if (mse_out && last_chunk && chunk <= kHostTrace) {
+            // the usual call (a frame, or a batch of frames, of the host loop): trace and status word in one round trip
+            if (int rc = flush_sqerr(c)) return rc;
+            for (int got = 0; got < chunk;) {
+                const int slot = (first_iter + got) % c->trace_cap, run = std::min(chunk - got, c->trace_cap - slot);
+                S2D_HIP(c, hipMemcpyAsync(c->h_trace + got, c->d_sqerr_trace + slot, (size_t)run * sizeof(double),
+                                          hipMemcpyDeviceToHost, c->stream));
+                got += run;
+            }
+            S2D_HIP(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(DeviceStatus), hipMemcpyDeviceToHost, c->stream));
+            S2D_HIP(c, hipStreamSynchronize(c->stream));
+            for (int k = 0; k < chunk; k++) mse_out[done + k] = c->h_trace[k] / norm; // main.cpp:805
+            status_read = true;
+        } else if (mse_out) {
             if (int rc = s2d_get_sqerr_trace(c, first_iter, chunk, mse_out + done)) return rc;
             for (int k = 0; k < chunk; k++) mse_out[done + k] /= norm; // main.cpp:805
         }
         done += chunk;
     }
-    const int rc = check_status(c);
+    const int rc = status_read ? judge_status(c) : check_status(c);
     if (rc == S2D_E_NONFINITE && mse_out) {
         // The reference abort()s right after the Adam step of that iteration (main.cpp:752-785): its trace ends with
         // that iteration's line.  The kernels of the later iterations queued here did nothing; their entries are NaN.
