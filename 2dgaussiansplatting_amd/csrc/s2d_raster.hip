@@ -432,12 +432,13 @@ struct BwdShared {
     float4 e0[B]; // cc, ss, 2sc, cc - ss
     float4 e1[B]; // ss, cc, 1/sx^3, 1/sy^3
     unsigned long long mask[4 * B]; // [wave][entry]
-    // Partial gradients of the batch, 9 (+3 pad) floats per entry.  Deterministic mode: one slot per wave, plain
-    // stores, summed over the 4 waves in a fixed order by the flush.  Otherwise the four waves add into ONE slot
+    // Partial gradients of the batch, 9 floats per slot (+3 pad where one slot per entry is shared).  Deterministic mode:
+    // one slot per wave, plain stores, summed over the 4 waves in a fixed order by the flush.  Otherwise the four waves add into ONE slot
     // per entry with ds_add_f32 (eight lanes, eight addresses per wave and entry): the order of those four
     // additions is as free as the order of the global atomics that follow, and 9 KB less LDS per workgroup is
     // one to two more resident workgroups per CU.  The flush zeroes what it read.
-    float4 part[DET ? 4 : 1][B][3];
+    static constexpr int kPartStride = DET ? 9 : 12; // floats per slot (deterministic mode packs its four slots per entry tightly)
+    __attribute__((aligned(16))) float part[(DET ? 4 : 1) * B * kPartStride];
     unsigned long long touched[4]; // bit e: wave w wrote slot e in this batch
     double red[4];
     int4 alive;                    // per wave: does it still have a live pixel (block_any_alive)
@@ -472,7 +473,7 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
         if (lane == 0) s.red[w] = e2;
     }
     if (!DET)
-        for (int i = tid; i < B * 3; i += 256) s.part[0][i / 3][i % 3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < B * 3; i += 256) reinterpret_cast<float4*>(s.part)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     if (sq.out == nullptr) {
         if (tid == 0) tile_sqerr[c.tile] = ((s.red[0] + s.red[1]) + s.red[2]) + s.red[3];
@@ -611,9 +612,9 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
                 // slot of (wave, entry, component), 12 dwords per entry.  The entry's share of the index is computed on the
                 // scalar unit explicitly: left to itself the compiler folds e * 12 + lane term into a per-lane
                 // v_mad_u64_u32 in the blend loop.
-                float* const part = reinterpret_cast<float*>(&s.part[0][0][0]);
+                float* const part = s.part;
                 int pe;
-                asm("s_mul_i32 %0, %1, 12" : "=s"(pe) : "s"((DET ? __builtin_amdgcn_readfirstlane(w) : 0) * B + e));
+                asm("s_mul_i32 %0, %1, %2" : "=s"(pe) : "s"((DET ? __builtin_amdgcn_readfirstlane(w) : 0) * B + e), "n"(BwdShared<DET>::kPartStride));
                 if (DET) {
                     if ((lane & 7) == 0) part[pe + part_slot] = tot;
                     if (NEED_OP && lane == 63) part[pe + 8] = g_op;
@@ -636,11 +637,11 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
 #pragma unroll
                 for (int ww = 0; ww < (DET ? 4 : 1); ww++)
                     if ((s.touched[ww] >> e) & 1ull) {
-                        v += reinterpret_cast<const float*>(&s.part[ww][e][0])[k];
+                        v += s.part[(ww * B + e) * BwdShared<DET>::kPartStride + k];
                         any_w = true;
                     }
             } else {
-                float* slot = reinterpret_cast<float*>(&s.part[0][e][0]) + k;
+                float* slot = s.part + e * BwdShared<DET>::kPartStride + k;
                 v = *slot;
                 *slot = 0.0f; // the next batch's waves add after the staging barrier
                 any_w = true;
