@@ -89,7 +89,7 @@ typedef enum s2d_status {
 #define S2D_CFG_DETERMINISTIC 0x4u /* bitwise reproducible gradients: tiles store their per-splat partial sums into
                                     * private slots and a gather pass adds them in a fixed order, instead of float
                                     * atomics whose arrival order varies from run to run (the forward pass is
-                                    * deterministic either way).  About a quarter slower at 4096^2 / 10^6 splats. */
+                                    * deterministic either way).  About a sixth slower at 4096^2 / 10^6 splats. */
 #define S2D_CFG_EXACT_EXP 0x8u     /* validation mode: exp_approx returns expf(x), the switch the reference keeps at
                                     * main.cpp:51 "for numerical varidation".  The analytic gradients (main.cpp:639-704)
                                     * are those of the true exponential, so in this mode the backward pass is the
