@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _build
 
-__all__ = ["Trainer", "S2DError", "load_library", "SPLAT_DTYPE", "ADAM_DTYPE", "STATUS_NAMES"]
+__all__ = ["Trainer", "MultiTrainer", "S2DError", "load_library", "SPLAT_DTYPE", "ADAM_DTYPE", "STATUS_NAMES"]
 
 # == struct Splat (main.cpp:85-93), 36 bytes; == struct SplatAdam (main.cpp:158-166), 72 bytes
 SPLAT_DTYPE = np.dtype([("pos", "<f4", 2), ("sx", "<f4"), ("sy", "<f4"), ("rot", "<f4"),
@@ -70,6 +70,9 @@ ABI_SYMBOLS = [
     "s2d_last_error", "s2d_test_sincos", "s2d_test_sort_pairs", "s2d_test_exclusive_scan",
     "s2d_debug_get_tile_lists",
     "s2d_halo_masks", "s2d_halo_commit", "s2d_rows_gather", "s2d_rows_scatter", "s2d_grads_combine",
+    "s2d_multi_create", "s2d_multi_destroy", "s2d_multi_last_error", "s2d_multi_device_count", "s2d_multi_set_target",
+    "s2d_multi_set_target_synthetic", "s2d_multi_init_splats", "s2d_multi_set_splats", "s2d_multi_get_splats",
+    "s2d_multi_set_adam", "s2d_multi_get_adam", "s2d_multi_step", "s2d_multi_get_image",
 ]
 
 _lib = None
@@ -134,6 +137,21 @@ def load_library(path=None):
     sig("s2d_rows_gather", [vp, i32, vp, i32, vp])
     sig("s2d_rows_scatter", [vp, i32, vp, i32, vp])
     sig("s2d_grads_combine", [vp, vp, i32, vp, i32, vp])
+    sig("s2d_multi_create", [C.POINTER(_Config), vp, i32, u32, C.POINTER(vp)])
+    sig("s2d_multi_destroy", [vp])
+    if hasattr(L, "s2d_multi_destroy"):
+        L.s2d_multi_destroy.restype = None
+    sig("s2d_multi_last_error", [vp], restype=C.c_char_p)
+    sig("s2d_multi_device_count", [vp])
+    sig("s2d_multi_set_target", [vp, vp])
+    sig("s2d_multi_set_target_synthetic", [vp])
+    sig("s2d_multi_init_splats", [vp])
+    sig("s2d_multi_set_splats", [vp, vp])
+    sig("s2d_multi_get_splats", [vp, vp])
+    sig("s2d_multi_set_adam", [vp, vp, C.c_float, C.c_float, i32])
+    sig("s2d_multi_get_adam", [vp, vp, vp, vp, vp])
+    sig("s2d_multi_step", [vp, i32, u32, vp])
+    sig("s2d_multi_get_image", [vp, vp])
     if path == _build.LIB_PATH:
         _lib = L
     return L
@@ -338,3 +356,94 @@ class Trainer:
         self._ck(self.L.s2d_debug_get_tile_lists(self._h, C.byref(tx), C.byref(ty), _p(off), len(off),
                                                  _p(lst), len(lst)))
         return tx.value, ty.value, off, lst[:int(st["pairs_binned"])]
+
+
+class MultiTrainer:
+    """Several GPUs behind one handle (s2d_multi_*, csrc/s2d_multi.hip): the Trainer's state and step() on a list of
+    devices -- row slabs, replicated state, RCCL all-reduce of the gradients, all inside the library.  share_gpu: every
+    rank on devices[0] with a host-staged gradient sum (a rehearsal where there are fewer GPUs than ranks)."""
+
+    def __init__(self, width, height, n_splats, devices, share_gpu=False, training_rate=0.0, rebin_interval=0,
+                 fp16_images=False, deterministic=False):
+        self.L = load_library()
+        self.W, self.H, self.n = int(width), int(height), int(n_splats)
+        cfg = _Config()
+        cfg.struct_size = C.sizeof(_Config)
+        cfg.width, cfg.height, cfg.n_splats = self.W, self.H, self.n
+        cfg.training_rate = float(training_rate)
+        cfg.rebin_interval = int(rebin_interval)
+        cfg.flags = (S2D_CFG_FP16_IMAGES if fp16_images else 0) | (S2D_CFG_DETERMINISTIC if deterministic else 0)
+        devs = (C.c_int32 * len(devices))(*devices)
+        h = C.c_void_p()
+        rc = self.L.s2d_multi_create(C.byref(cfg), devs, len(devices), 1 if share_gpu else 0, C.byref(h))
+        self._h = h
+        if rc != 0:
+            msg = self.L.s2d_multi_last_error(h).decode() if h else "s2d_multi_create rejected the configuration"
+            if h:
+                self.L.s2d_multi_destroy(h)
+            self._h = None
+            raise S2DError(rc, msg)
+        self.optimize_opacity = False
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.s2d_multi_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise S2DError(rc, self.L.s2d_multi_last_error(self._h).decode())
+
+    def set_target(self, rgba32f):
+        a = np.ascontiguousarray(rgba32f, dtype=np.float32)
+        assert a.shape == (self.H, self.W, 4), a.shape
+        self._ck(self.L.s2d_multi_set_target(self._h, _p(a)))
+
+    def set_target_synthetic(self):
+        self._ck(self.L.s2d_multi_set_target_synthetic(self._h))
+
+    def init(self):
+        self._ck(self.L.s2d_multi_init_splats(self._h))
+
+    def set_splats(self, splats):
+        a = np.ascontiguousarray(splats, dtype=SPLAT_DTYPE)
+        assert a.shape == (self.n,)
+        self._ck(self.L.s2d_multi_set_splats(self._h, _p(a)))
+
+    def get_splats(self):
+        a = np.zeros(self.n, dtype=SPLAT_DTYPE)
+        self._ck(self.L.s2d_multi_get_splats(self._h, _p(a)))
+        return a
+
+    def get_adam(self):
+        a = np.zeros(self.n, dtype=ADAM_DTYPE)
+        b1, b2, it = C.c_float(), C.c_float(), C.c_int32()
+        self._ck(self.L.s2d_multi_get_adam(self._h, _p(a), C.byref(b1), C.byref(b2), C.byref(it)))
+        return a, np.float32(b1.value), np.float32(b2.value), it.value
+
+    def set_adam(self, adams, beta1t, beta2t, iterations):
+        a = np.ascontiguousarray(adams, dtype=ADAM_DTYPE)
+        self._ck(self.L.s2d_multi_set_adam(self._h, _p(a), float(beta1t), float(beta2t), int(iterations)))
+
+    def step(self, iters=1, want_mse=True):
+        out = np.zeros(iters, dtype=np.float64) if want_mse else None
+        flags = S2D_STEP_OPTIMIZE_OPACITY if self.optimize_opacity else 0
+        self._ck(self.L.s2d_multi_step(self._h, int(iters), flags, _p(out) if want_mse else None))
+        return out
+
+    def get_image(self):
+        a = np.zeros((self.H, self.W, 4), dtype=np.float32)
+        self._ck(self.L.s2d_multi_get_image(self._h, _p(a)))
+        return a

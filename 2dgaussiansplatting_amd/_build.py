@@ -16,13 +16,14 @@ LIB_PATH = os.path.join(LIB_DIR, "libsplat2d_hip.so")
 HOST_DIR = os.path.join(PKG_DIR, "host")
 TRAIN_BIN = os.path.join(LIB_DIR, "splat2d_train")
 
-HIP_SOURCES = ["s2d_api.hip", "s2d_scan_sort.hip", "s2d_binning.hip", "s2d_raster.hip", "s2d_optim.hip", "s2d_halo.hip"]
+HIP_SOURCES = ["s2d_api.hip", "s2d_scan_sort.hip", "s2d_binning.hip", "s2d_raster.hip", "s2d_optim.hip", "s2d_halo.hip",
+               "s2d_multi.hip"]
 HIP_HEADERS = ["s2d_device.h", "s2d_math.h"]
 
 # -ffp-contract=off: the kernels keep the reference's evaluation order (no FMA contraction) wherever a
 # discrete decision or the framebuffer depends on it; fp32 divide/sqrt stay correctly rounded (hipcc default).
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function", "-pthread", "-ldl"]
 
 
 def kernel_source_digest():
@@ -77,11 +78,8 @@ def build_host_program(force=False, verbose=False):
             os.path.join(ROOT, "include", "splat2d.h"), LIB_PATH]
     if force or _stale(TRAIN_BIN, deps):
         rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-        # rccl.h pulls in the HIP runtime API header: plain C declarations, fine for g++ (no device code in the host)
-        cmd = ["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
-               "-I", os.path.join(rocm, "include"), "-o", TRAIN_BIN, src,
-               "-L", LIB_DIR, "-lsplat2d_hip", "-L", os.path.join(rocm, "lib"), "-lrccl", "-lamdhip64", "-lz", "-lpthread",
-               "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
+        cmd = ["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-o", TRAIN_BIN, src,
+               "-L", LIB_DIR, "-lsplat2d_hip", "-lz", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath," + os.path.join(rocm, "lib")]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

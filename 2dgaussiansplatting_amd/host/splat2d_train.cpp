@@ -12,24 +12,16 @@
 //   splat2d_train --synthetic 4096x4096 --splats 1000000 --iters 100 --quiet
 //   splat2d_train --synthetic 4096x4096 --splats 1000000 --iters 100 --quiet --gpus 8
 //
-// --gpus N (north_star's scheme): one host thread and one library context per GPU, the image cut
-// into N row slabs, splats and Adam state replicated; per iteration every context rasterises its slab forward and
-// backward, the N x 9 fp32 gradient array is all-reduced in place with RCCL over xGMI (ncclAllReduce on the
-// context's own stream, between s2d_forward_backward and s2d_adam_step), and every context applies the identical Adam
-// step, so the replicas stay bit-identical.  Partial squared errors are summed on the host for the trace line.
-#include <atomic>
+// --gpus N (north_star's scheme): the same loop on a multi-device handle (s2d_multi_*): the image
+// cut into N row slabs, splats and Adam state replicated, the N x 9 fp32 gradient arrays all-reduced in place with
+// RCCL over xGMI between the backward pass and the Adam step -- all inside the library.
 #include <chrono>
-#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <mutex>
 #include <string>
-#include <thread>
 #include <vector>
-
-#include <rccl/rccl.h>
 
 #include "image_io.h"
 #include "overlay.h"
@@ -90,177 +82,49 @@ int usage()
         }                                                                               \
     } while (0)
 
-// ---- --gpus N: row slabs, replicated state, RCCL all-reduce of the gradients --------------------------------------
-// Rows [r0, r1) of rank `rank`: whole 16-pixel tile rows, as even as possible (== distributed.slab_rows).
-void slab_rows(int height, int rank, int world, int* r0, int* r1)
-{
-    const int tile_rows = (height + 15) / 16;
-    *r0 = (int)((long long)tile_rows * rank / world) * 16;
-    *r1 = (int)((long long)tile_rows * (rank + 1) / world) * 16;
-    if (*r1 > height) *r1 = height;
-}
-
-// A reusable barrier for the rank threads (std::barrier is C++20).
-struct Barrier {
-    std::mutex m;
-    std::condition_variable cv;
-    int n, waiting = 0, generation = 0;
-    bool broken = false; // a rank failed: nobody waits for it any more
-    explicit Barrier(int n_) : n(n_) {}
-    void wait()
-    {
-        std::unique_lock<std::mutex> lk(m);
-        if (broken) return;
-        const int gen = generation;
-        if (++waiting == n) {
-            waiting = 0;
-            generation++;
-            cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return gen != generation || broken; });
-        }
-    }
-    void abort()
-    {
-        std::lock_guard<std::mutex> lk(m);
-        broken = true;
-        cv.notify_all();
-    }
-};
-
-struct MultiShared {
-    Barrier barrier;
-    std::vector<float*> host_grads;         // --share-gpu: pinned host copies of the ranks' partial gradients; [0] receives the sum
-    std::vector<std::vector<double>> sqerr; // [rank][iteration in batch]: partial squared errors (not yet normalised)
-    std::atomic<int> failed{0};             // first failing status (any rank): everyone stops at the next barrier
-    std::string error;
-    std::mutex err_mutex;
-    explicit MultiShared(int world) : barrier(world), host_grads((size_t)world, nullptr), sqerr((size_t)world) {}
-};
-
-// --share-gpu: the sum RCCL would form, through host memory.  Every rank copies its partial gradients out, rank 0 adds
-// them in rank order, every rank copies the sum back in.  Same result on every rank, like an all-reduce.
-bool staged_all_reduce(MultiShared& sh, int rank, int world, float* grads, size_t count, hipStream_t stream)
-{
-    bool ok = hipMemcpyAsync(sh.host_grads[(size_t)rank], grads, count * sizeof(float), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-              hipStreamSynchronize(stream) == hipSuccess;
-    sh.barrier.wait();
-    if (rank == 0)
-        for (int q = 1; q < world; q++) {
-            const float* src = sh.host_grads[(size_t)q];
-            float* dst = sh.host_grads[0];
-            for (size_t k = 0; k < count; k++) dst[k] += src[k];
-        }
-    sh.barrier.wait();
-    ok = ok && hipMemcpyAsync(grads, sh.host_grads[0], count * sizeof(float), hipMemcpyHostToDevice, stream) == hipSuccess &&
-         hipStreamSynchronize(stream) == hipSuccess;
-    sh.barrier.wait(); // nobody overwrites its host copy before everybody has read the sum
-    return ok;
-}
-
+// ---- --gpus N: the same frame loop on a multi-device handle (s2d_multi_*, csrc/s2d_multi.hip) ----------------------
 int run_multi(const Options& o, int W, int H, const std::vector<float>& imageRef)
 {
-    const int world = o.gpus;
-    std::vector<int> devs((size_t)world);
-    for (int r = 0; r < world; r++) devs[(size_t)r] = o.share_gpu ? o.device : o.device + r;
-    std::vector<ncclComm_t> comms((size_t)world, nullptr);
-    ncclResult_t nrc = ncclSuccess;
-    MultiShared sh(world);
-    if (!o.share_gpu) {
-        nrc = ncclCommInitAll(comms.data(), world, devs.data());
-        if (nrc != ncclSuccess) {
-            std::fprintf(stderr, "ncclCommInitAll(%d devices from %d): %s\n", world, o.device, ncclGetErrorString(nrc));
-            return 1;
-        }
-    } else {
-        for (int r = 0; r < world; r++)
-            if (hipHostMalloc((void**)&sh.host_grads[(size_t)r], (size_t)o.n_splats * 9 * sizeof(float) + 16, hipHostMallocDefault) != hipSuccess) {
-                std::fprintf(stderr, "--share-gpu: cannot allocate the host staging buffers\n");
-                return 1;
-            }
-    }
-    std::vector<s2d_splat> final_splats;
+    std::vector<int32_t> devs((size_t)o.gpus);
+    for (int r = 0; r < o.gpus; r++) devs[(size_t)r] = o.device + (o.share_gpu ? 0 : r);
+    s2d_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = sizeof(cfg);
+    cfg.width = W;
+    cfg.height = H;
+    cfg.n_splats = o.n_splats;
+    cfg.rebin_interval = o.rebin_interval;
+    s2d_multi* m = nullptr;
+#define CKM(call)                                                                         \
+    do {                                                                                  \
+        int rc_ = (call);                                                                 \
+        if (rc_ != S2D_OK) {                                                              \
+            std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, s2d_multi_last_error(m));  \
+            if (m) s2d_multi_destroy(m);                                                  \
+            return rc_ == S2D_E_NONFINITE ? 3 : 1; /* the reference abort()s */           \
+        }                                                                                 \
+    } while (0)
+    CKM(s2d_multi_create(&cfg, devs.data(), o.gpus, o.share_gpu ? S2D_MULTI_SHARE_GPU : 0u, &m));
+    if (imageRef.empty()) CKM(s2d_multi_set_target_synthetic(m));
+    else CKM(s2d_multi_set_target(m, imageRef.data()));
+    CKM(s2d_multi_init_splats(m)); // init(); main.cpp:307
+    std::vector<double> mse((size_t)o.batch);
     const auto t0 = std::chrono::steady_clock::now();
-    auto rank_main = [&](int rank) {
-        s2d_ctx* ctx = nullptr;
-        auto fail = [&](const char* what, int rc) {
-            std::lock_guard<std::mutex> lk(sh.err_mutex);
-            if (!sh.failed.exchange(rc == S2D_E_NONFINITE ? 3 : 1))
-                sh.error = std::string(what) + " on rank " + std::to_string(rank) + ": " + (ctx ? s2d_last_error(ctx) : "no context");
-            sh.barrier.abort(); // the other ranks stop at their next barrier instead of waiting for this one
-        };
-        s2d_config cfg;
-        std::memset(&cfg, 0, sizeof(cfg));
-        cfg.struct_size = sizeof(cfg);
-        cfg.width = W;
-        cfg.height = H;
-        cfg.n_splats = o.n_splats;
-        cfg.device = devs[(size_t)rank];
-        cfg.rebin_interval = o.rebin_interval;
-        slab_rows(H, rank, world, &cfg.row_begin, &cfg.row_end);
-        int rc = cfg.row_begin < cfg.row_end ? s2d_create(&cfg, &ctx) : S2D_E_INVALID; // more ranks than tile rows
-        if (rc == S2D_OK) rc = imageRef.empty() ? s2d_set_target_synthetic(ctx) : s2d_set_target(ctx, imageRef.data());
-        if (rc == S2D_OK) rc = s2d_init_splats(ctx); // every rank: the same deterministic init(), main.cpp:280-305
-        if (rc != S2D_OK) fail("setup", rc);
-        const uint32_t step_flags = o.optimize_opacity ? S2D_STEP_OPTIMIZE_OPACITY : 0u;
-        const uint32_t bwd_flags = o.optimize_opacity ? 0u : S2D_BWD_SKIP_OPACITY_GRAD; // Adam never reads it (main.cpp:735)
-        void* stream = ctx ? s2d_stream(ctx) : nullptr;
-        float* grads = ctx ? (float*)s2d_grads_device_ptr(ctx) : nullptr;
-        std::vector<double>& mine = sh.sqerr[(size_t)rank];
-        mine.assign((size_t)o.batch, 0.0);
-        int iterations = 0;
-        sh.barrier.wait();
-        while (iterations < o.iters && !sh.failed.load()) {
-            int k = o.batch;
-            if (k > o.iters - iterations) k = o.iters - iterations;
-            for (int j = 0; j < k && rc == S2D_OK && !sh.failed.load(); j++) { // one frame of main.cpp:334, this rank's rows
-                rc = s2d_forward_backward(ctx, bwd_flags);
-                if (rc == S2D_OK) {
-                    // the only exchange of the iteration: sum of the slabs' partial gradients, in place, on the stream the
-                    // kernels run on (RCCL over xGMI)
-                    if (!o.share_gpu) {
-                        nrc = ncclAllReduce(grads, grads, (size_t)o.n_splats * 9, ncclFloat, ncclSum, comms[(size_t)rank], (hipStream_t)stream);
-                        if (nrc != ncclSuccess) rc = S2D_E_HIP;
-                    } else if (!staged_all_reduce(sh, rank, world, grads, (size_t)o.n_splats * 9, (hipStream_t)stream)) {
-                        rc = S2D_E_HIP;
-                    }
-                }
-                if (rc == S2D_OK) rc = s2d_adam_step(ctx, step_flags);
-            }
-            if (rc == S2D_OK) rc = s2d_get_sqerr_trace(ctx, iterations, k, mine.data()); // synchronises the stream
-            if (rc == S2D_OK) rc = s2d_synchronize(ctx);                                   // non-finite guard, main.cpp:752-785
-            if (rc != S2D_OK) fail("iteration", rc);
-            sh.barrier.wait();
-            if (rank == 0 && !o.quiet && !sh.failed.load())
-                for (int j = 0; j < k; j++) {
-                    double sum = 0.0;
-                    for (int q = 0; q < world; q++) sum += sh.sqerr[(size_t)q][(size_t)j];
-                    std::printf("%d itr, mse %.4f\n", iterations + j, sum / ((double)H * W * 3)); // main.cpp:805-807
-                }
-            sh.barrier.wait();
-            iterations += k;
-        }
-        if (rank == 0 && ctx && !sh.failed.load()) {
-            final_splats.resize((size_t)o.n_splats);
-            if (s2d_get_splats(ctx, final_splats.data()) != S2D_OK) fail("s2d_get_splats", 1);
-        }
-        if (ctx) s2d_destroy(ctx);
-    };
-    std::vector<std::thread> threads;
-    for (int r = 0; r < world; r++) threads.emplace_back(rank_main, r);
-    for (auto& t : threads) t.join();
-    for (auto& c : comms)
-        if (c) ncclCommDestroy(c);
-    for (float* p : sh.host_grads)
-        if (p) (void)hipHostFree(p);
-    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    if (sh.failed.load()) {
-        std::fprintf(stderr, "%s\n", sh.error.c_str());
-        return sh.failed.load();
+    int iterations = 0;
+    while (iterations < o.iters) { // while (pr::NextFrame() == false), main.cpp:334
+        int k = o.batch;
+        if (k > o.iters - iterations) k = o.iters - iterations;
+        CKM(s2d_multi_step(m, k, o.optimize_opacity ? S2D_STEP_OPTIMIZE_OPACITY : 0u, mse.data()));
+        if (!o.quiet)
+            for (int j = 0; j < k; j++) std::printf("%d itr, mse %.4f\n", iterations + j, mse[(size_t)j]); // main.cpp:807
+        iterations += k;
     }
-    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats, %d ranks: row slabs + %s of the gradients; "
-                         "includes context set-up)\n", o.iters, secs, secs > 0 ? o.iters / secs : 0.0, W, H, o.n_splats, world,
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats, %d ranks: row slabs + %s of the gradients)\n",
+                 o.iters, secs, secs > 0 ? o.iters / secs : 0.0, W, H, o.n_splats, o.gpus,
                  o.share_gpu ? "host-staged sum (ranks share one GPU)" : "RCCL all-reduce");
+#undef CKM
+    s2d_multi_destroy(m);
     return 0;
 }
 
@@ -325,7 +189,7 @@ int main(int argc, char** argv)
     }
 
     if (o.gpus < 1) return usage();
-    if (o.gpus > 1 || std::getenv("S2D_TRAIN_FORCE_RCCL")) { // (the variable sends --gpus 1 through the RCCL path: a one-GPU rehearsal)
+    if (o.gpus > 1 || std::getenv("S2D_TRAIN_FORCE_MULTI")) { // (the variable sends --gpus 1 through the multi-device handle)
         if (!o.load_ckpt.empty() || !o.save_ckpt.empty() || !o.out_image.empty() || !o.overlay.empty() || o.restart_at >= 0 ||
             o.opacity_from > 0) {
             std::fprintf(stderr, "--gpus: checkpoints, image output, --restart-at and --opacity-from are single-GPU options\n");

@@ -229,6 +229,34 @@ void* s2d_stream(s2d_ctx* ctx);
 int s2d_get_sqerr_trace(s2d_ctx* ctx, int32_t first_iteration, int32_t count, double* out);
 int s2d_synchronize(s2d_ctx* ctx);
 
+/* ---- several GPUs behind one handle ("device list ...; multi-GPU fan-out is internal") -------------
+ * s2d_multi keeps the single-threaded call pattern of main.cpp:334 and runs it on n_devices GPUs: the image is cut into
+ * n_devices row slabs (whole 16-pixel tile rows), every device gets an ordinary context for its slab with splats and Adam
+ * state replicated, and per iteration every device rasterises its rows forward and backward, the N x 9 fp32 gradient
+ * arrays are summed in place by an RCCL all-reduce over xGMI (on each context's stream, between s2d_forward_backward and
+ * s2d_adam_step), and every device applies the identical Adam step.  One worker thread per device inside; the caller
+ * needs none.  cfg: as for s2d_create, with device / row_begin / row_end / stream unused (must be 0).  RCCL is loaded
+ * (dlopen) when the first handle with more than one device is created. */
+#define S2D_MULTI_SHARE_GPU 0x1u /* rehearsal on a box with fewer GPUs than ranks (RCCL takes one rank per GPU): all ranks on
+                                  * devices[0], the gradient sum staged through pinned host memory in rank order */
+typedef struct s2d_multi s2d_multi;
+int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_devices, uint32_t flags, s2d_multi** out);
+void s2d_multi_destroy(s2d_multi* m);
+const char* s2d_multi_last_error(const s2d_multi* m);
+int s2d_multi_device_count(const s2d_multi* m);
+int s2d_multi_set_target(s2d_multi* m, const float* rgba32f);         /* imageRef, main.cpp:254-259, to every replica */
+int s2d_multi_set_target_synthetic(s2d_multi* m);
+int s2d_multi_init_splats(s2d_multi* m);                              /* init(), main.cpp:280-305, on every replica */
+int s2d_multi_set_splats(s2d_multi* m, const s2d_splat* splats);
+int s2d_multi_get_splats(s2d_multi* m, s2d_splat* splats);            /* the replicas are bit-identical: replica 0's */
+int s2d_multi_set_adam(s2d_multi* m, const s2d_splat_adam* adams, float beta1t, float beta2t, int32_t iterations);
+int s2d_multi_get_adam(s2d_multi* m, s2d_splat_adam* adams, float* beta1t, float* beta2t, int32_t* iterations);
+/* `iters` whole iterations (main.cpp:414-809) on all devices; mse_out as for s2d_step (the slabs' squared errors are
+ * added in slab order).  S2D_E_NONFINITE where the reference would abort(). */
+int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out);
+/* image0 of the last iteration of the last s2d_multi_step, assembled from the slabs. */
+int s2d_multi_get_image(s2d_multi* m, float* rgba32f);
+
 int s2d_get_stats(s2d_ctx* ctx, s2d_stats* out);
 /* s2d_stats.rebins without the device round trip s2d_get_stats makes (a host-side counter; never synchronises). */
 int s2d_get_rebuild_count(const s2d_ctx* ctx, uint64_t* rebuilds);

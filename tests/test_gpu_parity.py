@@ -1052,15 +1052,16 @@ def test_step_leaves_the_image_of_its_last_iteration():
 
 
 def test_cpp_host_multi_gpu_path_through_rccl_on_one_gpu():
-    """host/splat2d_train.cpp --gpus N: one thread + one context per GPU, ncclAllReduce of the N x 9 gradients between
-    s2d_forward_backward and s2d_adam_step.  This box has one GPU (RCCL takes one rank per GPU), so the test sends
-    --gpus 1 through that same code (S2D_TRAIN_FORCE_RCCL): communicator set-up, the in-place all-reduce on the
-    context's stream, the host-side sum of the slabs' squared errors and the reference's trace line."""
+    """host/splat2d_train.cpp --gpus N drives a multi-device handle (s2d_multi_*): one worker thread + one context per
+    GPU, ncclAllReduce of the N x 9 gradients between s2d_forward_backward and s2d_adam_step.  This box has one GPU
+    (RCCL takes one rank per GPU), so the test sends --gpus 1 through that same code (S2D_TRAIN_FORCE_MULTI): RCCL
+    loaded with dlopen, communicator set-up, the in-place all-reduce on the context's stream, the sum of the slabs'
+    squared errors and the reference's trace line."""
     import subprocess
     exe = os.path.join(os.path.dirname(S2D.__file__), "lib", "splat2d_train")
     args = [exe, "--image", MINI, "--splats", "1024", "--iters", "12", "--batch", "4"]
     want = subprocess.run(args, capture_output=True, text=True, check=True).stdout.strip().splitlines()
-    env = dict(os.environ, S2D_TRAIN_FORCE_RCCL="1")
+    env = dict(os.environ, S2D_TRAIN_FORCE_MULTI="1")
     p = subprocess.run(args + ["--gpus", "1"], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     got = [ln for ln in p.stdout.strip().splitlines() if " itr, mse " in ln]
@@ -1106,3 +1107,52 @@ def test_cpp_host_n_ranks_sharing_the_gpu(world):
     assert len(got) == 12 and got[0] == "0 itr, mse 5934.9042"
     np.testing.assert_allclose([float(l.split("mse")[1]) for l in got], [float(l.split("mse")[1]) for l in want], rtol=2e-5)
     assert "%d ranks" % world in p.stderr
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_device_handle_ranks_sharing_the_gpu(world):
+    """s2d_multi_* (several GPUs behind one handle: the fan-out SURVEY.md section 8b asks for) with all ranks on this
+    box's one GPU (S2D_MULTI_SHARE_GPU: host-staged gradient sum): the first frame is bit-identical to the single
+    context's (same init(), same rows), the trace follows it (only the fp32 order of the gradient sums differs), the
+    replicas' state comes back through the handle, and a deterministic handle reproduces itself bit for bit."""
+    tgt = mini_target()
+    with S2D.Trainer(268, 213, 1500) as t:
+        t.set_target(tgt)
+        t.init()
+        want0 = t.step(1)
+        want_img = t.get_image()
+        want = np.concatenate([want0, t.step(9)])
+        want_splats = t.get_splats().view(np.float32)
+    res = []
+    for rep in range(2):
+        with S2D.MultiTrainer(268, 213, 1500, [0] * world, share_gpu=True, deterministic=True) as m:
+            m.set_target(tgt)
+            m.init()
+            got0 = m.step(1)
+            img = m.get_image()
+            got = np.concatenate([got0, m.step(4), m.step(5)])
+            sp = m.get_splats()
+            ad, b1, b2, it = m.get_adam()
+            res.append((got.tobytes(), sp.tobytes(), ad.tobytes()))
+        assert it == 10
+        assert img.tobytes() == want_img.tobytes()
+        assert abs(got[0] - want[0]) <= 1e-12 * want[0]
+        np.testing.assert_allclose(got, want, rtol=2e-5)
+        np.testing.assert_allclose(sp.view(np.float32), want_splats, rtol=1e-3, atol=1e-3)
+    assert res[0] == res[1]
+    with pytest.raises(S2D.S2DError):
+        S2D.MultiTrainer(268, 213, 100, [0, 0])   # two ranks on one GPU without the rehearsal flag: RCCL refuses
+
+
+def test_multi_device_handle_reports_nonfinite_like_the_single_context():
+    tgt = mini_target()
+    with S2D.MultiTrainer(268, 213, 300, [0, 0], share_gpu=True) as m:
+        m.set_target(tgt)
+        m.init()
+        m.step(2)
+        ad, b1, b2, it = m.get_adam()
+        ad["mv"][5, 4, 0] = np.inf
+        m.set_adam(ad, b1, b2, it)
+        with pytest.raises(S2D.S2DError) as ei:
+            m.step(3)
+        assert ei.value.code == 3
