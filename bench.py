@@ -168,7 +168,10 @@ def main():
         sys.exit("RCCL needs one GPU per rank: %d ranks, %d GPUs" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(device)
     dist = None
-    if world > 1:
+    # S2D_BENCH_FORCE_DIST=1 (under a launcher with one rank): take the N > 1 code -- process group on RCCL, the
+    # collectives on the context's stream -- with a world of one; how a one-GPU box rehearses that path
+    use_dist = world > 1 or ("WORLD_SIZE" in os.environ and os.environ.get("S2D_BENCH_FORCE_DIST") == "1")
+    if use_dist:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -192,7 +195,7 @@ def main():
     t.set_target_synthetic()
     t.init()
 
-    exchange = args.exchange if world > 1 else "none"
+    exchange = args.exchange if use_dist else "none"
     if exchange == "halo" and not D.all_to_all_selftest(dist, "cuda"):
         # the collective pattern slab ownership needs misbehaved on this stack: every rank agreed (all-reduce) to
         # use the replicated-state scheme instead -- slower, same results
@@ -204,9 +207,9 @@ def main():
         step = D.HaloStep(t, D.HipHaloOps(t, n, "cuda"), dist, rank, world, H)
     else:
         # forward + backward, all-reduce(grads), Adam; every 64 iterations the replicas' parameter checksums are compared
-        ops = D.HipHaloOps(t, n, "cuda") if world > 1 else None
-        all_ids = torch.arange(n, dtype=torch.int32, device="cuda") if world > 1 else None
-        step = D.SlabStep(t, grads, dist, params=(lambda: ops.rows_gather(D.ROWS_SPLATS, all_ids)) if world > 1 else None,
+        ops = D.HipHaloOps(t, n, "cuda") if use_dist else None
+        all_ids = torch.arange(n, dtype=torch.int32, device="cuda") if use_dist else None
+        step = D.SlabStep(t, grads, dist, params=(lambda: ops.rows_gather(D.ROWS_SPLATS, all_ids)) if use_dist else None,
                           check_interval=64)
 
     def one_step(ev=None):
@@ -320,7 +323,7 @@ def main():
             "config": {"workload": "%dx%d synthetic RGB, %d Gaussians, fp32%s" % (W, H, n, " (BASELINE.json configs[3])" if (W, H, n) == (4096, 4096, 1000000) else ""),
                        "width": W, "height": H, "n_splats": n,
                        "parallelism": "rowslab%d%s" % (world, ("+%s-%s" % ("rccl" if args.backend == "nccl" else args.backend,
-                                                                              "halo-exchange" if exchange == "halo" else "allreduce-grads")) if world > 1 else ""),
+                                                                              "halo-exchange" if exchange == "halo" else "allreduce-grads")) if use_dist else ""),
                        "rebin_interval": args.rebin_interval},
             "mse_last": mse_last,
             "psnr_db_last": (10.0 * float(np.log10(255.0 ** 2 / mse_last)) if mse_last > 0 else None),
@@ -332,7 +335,7 @@ def main():
             "exchange_rank0": ({"scheme": "halo", "held_fraction": float(((step.mask >> rank) & 1).float().mean().item()),
                                 "rows_exchanged_per_iteration": int(sum(step.splits)), "state_handovers": int(step.handed_over)}
                                if isinstance(step, D.HaloStep) else
-                               {"scheme": "dense" if world > 1 else "none", "replica_checksum_checks": getattr(step, "checks", 0)}),
+                               {"scheme": "dense" if use_dist else "none", "replica_checksum_checks": getattr(step, "checks", 0)}),
             "pairs_binned_rank0": stats["pairs_binned"],
             "rebins_rank0": stats["rebins"],
             "roofline": {"bound": "hbm", "kernel": "raster_fused_kernel", "achieved": achieved, "peak": 8000.0,

@@ -275,6 +275,36 @@ def test_bench_plain_command_two_ranks_gloo():
     assert abs(psnr["halo"] - psnr["dense"]) < 0.05
 
 
+def test_bench_one_rank_through_rccl_as_the_driver_launches_it():
+    """The driver's N > 1 command (`python -m torch.distributed.run ... bench.py --gpus N`) with the one rank this box
+    can give RCCL, and S2D_BENCH_FORCE_DIST=1 so that the rank takes the N > 1 code: process group on RCCL bound to
+    the device, the all_to_all self-test, the collectives ordered on the context's stream (dense: the in-place
+    all-reduce of the gradients and the replica checksum; halo: hold sets and the refresh), the barrier around the timed
+    steps.  The result must be the single-process trajectory."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    common = ["--steps", "70", "--warmup", "2", "--width", "1024", "--height", "768", "--splats", "60000", "--no-cpu-baseline"]
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1"] + common, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    plain = json.loads(p.stdout.strip().splitlines()[-1])
+    assert plain["exchange_rank0"]["scheme"] == "none"
+    for k, exchange in enumerate(("dense", "halo")):
+        p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                            "127.0.0.1", "--master-port", str(29611 + k), os.path.join(root, "bench.py"), "--gpus", "1",
+                            "--exchange", exchange] + common, env=dict(env, S2D_BENCH_FORCE_DIST="1"), capture_output=True,
+                           text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, lines
+        out = json.loads(lines[0])
+        assert out["n_gpus"] == 1 and out["exchange_rank0"]["scheme"] == exchange, out["exchange_rank0"]
+        assert out["config"]["parallelism"].startswith("rowslab1+rccl-")
+        if exchange == "dense":
+            assert out["exchange_rank0"]["replica_checksum_checks"] >= 1
+        assert abs(out["psnr_db"] - plain["psnr_db"]) < 0.02, (out["psnr_db"], plain["psnr_db"])
+
+
 def _fp16(a):
     return a.astype(np.float16).astype(np.float32)
 
