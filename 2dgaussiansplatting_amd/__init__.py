@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "s2d_halo_masks", "s2d_halo_commit", "s2d_rows_gather", "s2d_rows_scatter", "s2d_grads_combine",
     "s2d_multi_create", "s2d_multi_destroy", "s2d_multi_last_error", "s2d_multi_device_count", "s2d_multi_set_target",
     "s2d_multi_set_target_synthetic", "s2d_multi_init_splats", "s2d_multi_set_splats", "s2d_multi_get_splats",
-    "s2d_multi_set_adam", "s2d_multi_get_adam", "s2d_multi_step", "s2d_multi_get_image",
+    "s2d_multi_set_adam", "s2d_multi_get_adam", "s2d_multi_step", "s2d_multi_get_image", "s2d_multi_exchange_info",
 ]
 
 _lib = None
@@ -152,6 +152,7 @@ def load_library(path=None):
     sig("s2d_multi_get_adam", [vp, vp, vp, vp, vp])
     sig("s2d_multi_step", [vp, i32, u32, vp])
     sig("s2d_multi_get_image", [vp, vp])
+    sig("s2d_multi_exchange_info", [vp, vp])
     if path == _build.LIB_PATH:
         _lib = L
     return L
@@ -360,11 +361,14 @@ class Trainer:
 
 class MultiTrainer:
     """Several GPUs behind one handle (s2d_multi_*, csrc/s2d_multi.hip): the Trainer's state and step() on a list of
-    devices -- row slabs, replicated state, RCCL all-reduce of the gradients, all inside the library.  share_gpu: every
-    rank on devices[0] with a host-staged gradient sum (a rehearsal where there are fewer GPUs than ranks)."""
+    devices -- row slabs and, inside the library, either slab ownership with peer-to-peer copies of the shared
+    gradient rows (default) or replicated state with an RCCL all-reduce of all gradients (replicated=True).
+    share_gpu: every rank on devices[0] (a rehearsal where there are fewer GPUs than ranks)."""
+
+    SCHEMES = {0: "none", 1: "ownership", 2: "replicated"}
 
     def __init__(self, width, height, n_splats, devices, share_gpu=False, training_rate=0.0, rebin_interval=0,
-                 fp16_images=False, deterministic=False):
+                 fp16_images=False, deterministic=False, replicated=False):
         self.L = load_library()
         self.W, self.H, self.n = int(width), int(height), int(n_splats)
         cfg = _Config()
@@ -375,7 +379,7 @@ class MultiTrainer:
         cfg.flags = (S2D_CFG_FP16_IMAGES if fp16_images else 0) | (S2D_CFG_DETERMINISTIC if deterministic else 0)
         devs = (C.c_int32 * len(devices))(*devices)
         h = C.c_void_p()
-        rc = self.L.s2d_multi_create(C.byref(cfg), devs, len(devices), 1 if share_gpu else 0, C.byref(h))
+        rc = self.L.s2d_multi_create(C.byref(cfg), devs, len(devices), (1 if share_gpu else 0) | (2 if replicated else 0), C.byref(h))
         self._h = h
         if rc != 0:
             msg = self.L.s2d_multi_last_error(h).decode() if h else "s2d_multi_create rejected the configuration"
@@ -447,3 +451,9 @@ class MultiTrainer:
         a = np.zeros((self.H, self.W, 4), dtype=np.float32)
         self._ck(self.L.s2d_multi_get_image(self._h, _p(a)))
         return a
+
+    def exchange_info(self):
+        """scheme, gradient rows swapped per iteration (all ranks), state rows handed over, splats held (all ranks)."""
+        a = np.zeros(4, dtype=np.int64)
+        self._ck(self.L.s2d_multi_exchange_info(self._h, _p(a)))
+        return {"scheme": self.SCHEMES[int(a[0])], "rows_per_iteration": int(a[1]), "state_handovers": int(a[2]), "held": int(a[3])}

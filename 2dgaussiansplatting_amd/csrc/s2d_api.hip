@@ -769,8 +769,21 @@ int s2d_halo_masks(s2d_ctx* c, int32_t world, const int32_t* row_bounds, float m
 
 int s2d_halo_commit(s2d_ctx* c, const uint32_t* masks_device, int32_t rank, int32_t added)
 {
-    if (!c || !masks_device || rank < 0 || rank > 31) return S2D_E_INVALID;
+    if (!c || rank < 0 || rank > 31) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
+    if (!masks_device) { // back to holding every splat (the caller has made this context's copy complete again)
+        if (c->d_held) {
+            S2D_HIP(c, hipStreamSynchronize(c->stream));
+            void* ptrs[] = {c->d_held, c->d_held_ids, c->d_held_work, c->d_held_count};
+            for (void* q : ptrs) (void)hipFree(q);
+            c->d_held = nullptr;
+            c->d_held_ids = c->d_held_work = c->d_held_count = nullptr;
+            c->lists_valid = false;
+            c->proj_fresh = false;
+            c->have_forward = c->have_backward = false;
+        }
+        return S2D_OK;
+    }
     const bool first = c->d_held == nullptr;
     if (first) {
         S2D_HIP(c, dev_alloc(&c->d_held, (size_t)c->n));

@@ -3,22 +3,29 @@
 //
 // A reference-side caller keeps its single-threaded frame loop (main.cpp:334) and gets N GPUs by swapping s2d_ctx for
 // s2d_multi: the image is cut into N row slabs (whole 16-pixel tile rows), every device gets an ordinary context for
-// its slab with the splats and the Adam state replicated, and per iteration every device rasterises its rows forward
-// and backward, the N x 9 fp32 gradient arrays are summed in place by an RCCL all-reduce over xGMI (ncclAllReduce on
-// each context's own stream, between s2d_forward_backward and s2d_adam_step), and every device applies the identical
-// Adam step -- so the replicas stay bit-identical without ever exchanging parameters or framebuffers (north_star's
-// scheme).  One worker thread per device keeps its context's calls in order; the caller's thread only hands out
-// commands and adds up the slabs' squared errors.  RCCL is loaded with dlopen when the first multi handle is created,
-// so single-GPU users of the library never load it.
+// its slab and one worker thread that keeps the context's calls in order; the caller's thread only hands out commands
+// and adds up the slabs' squared errors.  Two ways to keep the devices consistent:
 //
-// S2D_MULTI_SHARE_GPU (rehearsal on a box with fewer GPUs than ranks -- RCCL takes one rank per GPU): all ranks on the
-// first listed device, the gradient sum staged through pinned host memory in rank order.
+//  * slab ownership (default): a device holds -- projects, lists, updates -- only the splats that can reach its rows.
+//    Per iteration the holders of a shared splat swap its partial gradient rows (s2d_rows_gather into a send buffer,
+//    a peer-to-peer copy over xGMI queued on the RECEIVER's stream behind the sender's event, s2d_grads_combine in
+//    rank order, so every holder forms the same bits); every 64 iterations the hold sets are refreshed from the
+//    current parameters and the 27-float state of splats that drift into a neighbour's reach is handed over.  No
+//    collective library involved: neighbours talk to neighbours, ~1 MB per iteration instead of a 36 MB all-reduce.
+//  * replicated state (S2D_MULTI_REPLICATED, north_star's scheme): splats and Adam state on every device, the N x 9 fp32
+//    gradient arrays summed in place by an RCCL all-reduce (ncclAllReduce on each context's own stream, between
+//    s2d_forward_backward and s2d_adam_step), the identical Adam step everywhere.  RCCL is loaded with dlopen when
+//    such a handle is created, so other users of the library never load it.
+//
+// S2D_MULTI_SHARE_GPU (rehearsal on a box with fewer GPUs than ranks): all ranks on the first listed device; the peer
+// copies become plain device copies, the all-reduce is staged through pinned host memory in rank order.
 #include "../../include/splat2d.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h> // types only; the entry points are resolved at run time
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <cstdarg>
@@ -73,7 +80,7 @@ struct Barrier {
     std::mutex m;
     std::condition_variable cv;
     int n = 1, waiting = 0, generation = 0;
-    bool broken = false;
+    std::atomic<bool> broken{false};
     void wait()
     {
         std::unique_lock<std::mutex> lk(m);
@@ -101,19 +108,86 @@ struct Barrier {
     }
 };
 
-enum Command { CMD_NONE = 0, CMD_STEP, CMD_QUIT };
+enum Command { CMD_NONE = 0, CMD_STEP, CMD_HOLD, CMD_QUIT };
+enum Scheme { SCHEME_NONE = 0, SCHEME_OWNERSHIP = 1, SCHEME_REPLICATED = 2 };
+constexpr int kStopped = -1; // a rank that stopped because another one failed (never reported to the caller)
+
+// Device array that only grows (freed and re-allocated while the rank's stream is idle).
+template <typename T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t count)
+    {
+        if (count <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = std::max<size_t>(count + count / 4, 256);
+        const hipError_t e = hipMalloc((void**)&p, want * sizeof(T));
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// Slab ownership, one rank's side (the host logic of distributed.HaloStep, here inside the library).
+struct HaloRank {
+    std::vector<uint32_t> mask;           // per splat: bit q = rank q holds it; 0 = this rank does not (its copy is stale)
+    std::vector<int32_t> held;            // ascending ids with mask != 0
+    std::vector<int32_t> splits, offsets; // gradient rows swapped with each peer per iteration; where its segment starts
+    int total = 0, n_rows = 0;
+    bool any_exchange = false;            // some rank swaps something: everybody takes part in the per-iteration barrier
+    DevBuf<int32_t> d_send_ids, d_rows, d_src;
+    DevBuf<float> d_send[2], d_recv;      // two send buffers: a peer may still be copying iteration k while k + 1 is gathered
+    DevBuf<uint32_t> d_mask;              // n words: s2d_halo_masks output / s2d_halo_commit input
+    hipEvent_t ev_sent[2] = {nullptr, nullptr};
+    unsigned seq = 0;                     // exchanges since the hold sets were made (its parity picks the send buffer)
+    // a refresh: state rows on their way to ranks that newly hold a splat
+    std::vector<uint32_t> fresh;                 // masks from the current parameters (0 where not held)
+    std::vector<std::vector<int32_t>> out_ids;   // [destination rank]
+    std::vector<std::vector<uint32_t>> out_mask; // ... and the hold-set word the destination starts with
+    std::vector<int32_t> out_off;                // first payload row of each destination
+    DevBuf<int32_t> d_pay_ids, d_in_ids;
+    DevBuf<float> d_pay_sp, d_pay_ad, d_in_sp, d_in_ad;
+    long long handed = 0;                 // state rows sent or received so far (diagnostic)
+    void release()
+    {
+        d_send_ids.release(), d_rows.release(), d_src.release(), d_send[0].release(), d_send[1].release(), d_recv.release();
+        d_mask.release(), d_pay_ids.release(), d_in_ids.release(), d_pay_sp.release(), d_pay_ad.release(), d_in_sp.release();
+        d_in_ad.release();
+        for (hipEvent_t& e : ev_sent) {
+            if (e) (void)hipEventDestroy(e);
+            e = nullptr;
+        }
+    }
+};
 
 } // namespace
 
 struct s2d_multi {
     int world = 0, W = 0, H = 0, n = 0;
     bool share_gpu = false;
+    int scheme = SCHEME_NONE;
     std::vector<int> devices;
     std::vector<s2d_ctx*> ctx;
     std::vector<int> row_begin, row_end;
     Rccl rccl;
     std::vector<ncclComm_t> comms;
-    std::vector<float*> host_grads; // share-gpu: pinned copies of the ranks' partial gradients; [0] receives the sum
+    std::vector<float*> host_grads; // replicated + share-gpu: pinned copies of the ranks' partial gradients; [0] receives the sum
+    // slab ownership
+    std::vector<HaloRank> halo;
+    std::vector<int32_t> bounds;    // world + 1 row bounds
+    int interval = 64;              // iterations between refreshes of the hold sets
+    float margin = 0.0f;            // rows; must outlast one interval of Adam steps
+    bool hold_valid = false;        // hold sets exist (otherwise every context holds, and has, everything)
+    int hold_age = 0;               // iterations since they were made
+    std::atomic<int> late{0};
     // command hand-out
     std::vector<std::thread> workers;
     std::mutex m;
@@ -124,6 +198,7 @@ struct s2d_multi {
     int step_first_iter = 0;
     Barrier barrier;
     std::vector<int> rank_rc;
+    std::vector<std::string> rank_msg; // failures of this file's own HIP calls (the contexts keep theirs)
     std::vector<std::vector<double>> sqerr; // [rank][iteration of the call]: partial squared errors
     int iterations = 0;
     char err[512] = {0};
@@ -140,6 +215,23 @@ int mfail(s2d_multi* m, int code, const char* fmt, ...)
     return code;
 }
 
+int rank_fail(s2d_multi* m, int rank, int code, const char* fmt, ...)
+{
+    char buf[400];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    m->rank_msg[(size_t)rank] = buf;
+    return code;
+}
+
+#define MHIP(m, rank, call)                                                                               \
+    do {                                                                                                  \
+        const hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) return rank_fail((m), (rank), S2D_E_HIP, "%s: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
 // Rows [r0, r1) of rank `rank`: whole 16-pixel tile rows, as even as possible (== distributed.slab_rows).
 void slab_rows(int height, int rank, int world, int* r0, int* r1)
 {
@@ -149,8 +241,27 @@ void slab_rows(int height, int rank, int world, int* r0, int* r1)
     if (*r1 > height) *r1 = height;
 }
 
-// The sum RCCL would form, through host memory: every rank copies its partial gradients out, rank 0 adds them in rank
-// order, every rank copies the sum back in.
+// Barrier of the rank threads; false once some rank has failed (the caller stops).
+bool meet(s2d_multi* m)
+{
+    m->barrier.wait();
+    return !m->barrier.broken;
+}
+
+// Device-to-device copy between two ranks' buffers, queued on `stream` (the receiver's): over xGMI between two GPUs,
+// an ordinary device copy when the ranks share one.
+hipError_t rank_copy(s2d_multi* m, void* dst, int dst_rank, const void* src, int src_rank, size_t bytes, hipStream_t stream)
+{
+    if (bytes == 0) return hipSuccess;
+    const int dd = m->devices[(size_t)dst_rank], sd = m->devices[(size_t)src_rank];
+    if (dd == sd) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream);
+    return hipMemcpyPeerAsync(dst, dd, src, sd, bytes, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// replicated state: the sum RCCL would form, through host memory (S2D_MULTI_SHARE_GPU): every rank copies its partial
+// gradients out, rank 0 adds them in rank order, every rank copies the sum back in.
+// ---------------------------------------------------------------------------------------------------------------------
 bool staged_all_reduce(s2d_multi* m, int rank, float* grads, size_t count, hipStream_t stream)
 {
     bool ok = hipMemcpyAsync(m->host_grads[(size_t)rank], grads, count * sizeof(float), hipMemcpyDeviceToHost, stream) == hipSuccess &&
@@ -169,6 +280,258 @@ bool staged_all_reduce(s2d_multi* m, int rank, float* grads, size_t count, hipSt
     return ok;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// slab ownership
+// ---------------------------------------------------------------------------------------------------------------------
+// Exchange lists for the rank's current hold set: which gradient rows go to which peer (ascending ids per peer -- the
+// peer derives the same list from its identical mask words), and for every shared row where each holder's partial sits
+// in the receive buffer (s2d_grads_combine's table).
+int plan(s2d_multi* m, int r)
+{
+    HaloRank& H = m->halo[(size_t)r];
+    const int world = m->world;
+    const uint32_t me = 1u << r;
+    hipStream_t stream = (hipStream_t)s2d_stream(m->ctx[(size_t)r]);
+    std::vector<std::vector<int32_t>> peer((size_t)world);
+    std::vector<int32_t> rows, src;
+    for (const int32_t i : H.held) {
+        uint32_t others = H.mask[(size_t)i] & ~me;
+        if (!others) continue;
+        const size_t u = rows.size();
+        rows.push_back(i);
+        src.resize((u + 1) * (size_t)world, -1);
+        src[u * (size_t)world + (size_t)r] = -2;
+        while (others) {
+            const int p = __builtin_ctz(others);
+            others &= others - 1u;
+            src[u * (size_t)world + (size_t)p] = (int32_t)peer[(size_t)p].size(); // + the peer's offset, below
+            peer[(size_t)p].push_back(i);
+        }
+    }
+    H.splits.assign((size_t)world, 0);
+    H.offsets.assign((size_t)world, 0);
+    int total = 0;
+    for (int p = 0; p < world; p++) {
+        H.offsets[(size_t)p] = total;
+        H.splits[(size_t)p] = (int32_t)peer[(size_t)p].size();
+        total += H.splits[(size_t)p];
+    }
+    for (size_t u = 0; u < rows.size(); u++)
+        for (int p = 0; p < world; p++)
+            if (src[u * (size_t)world + (size_t)p] >= 0) src[u * (size_t)world + (size_t)p] += H.offsets[(size_t)p];
+    std::vector<int32_t> send_ids;
+    send_ids.reserve((size_t)total);
+    for (int p = 0; p < world; p++) send_ids.insert(send_ids.end(), peer[(size_t)p].begin(), peer[(size_t)p].end());
+    H.total = total;
+    H.n_rows = (int)rows.size();
+    H.seq = 0;
+    MHIP(m, r, H.d_send_ids.reserve((size_t)total));
+    MHIP(m, r, H.d_send[0].reserve((size_t)total * 9));
+    MHIP(m, r, H.d_send[1].reserve((size_t)total * 9));
+    MHIP(m, r, H.d_recv.reserve((size_t)total * 9));
+    MHIP(m, r, H.d_rows.reserve(rows.size()));
+    MHIP(m, r, H.d_src.reserve(src.size()));
+    if (total) MHIP(m, r, hipMemcpyAsync(H.d_send_ids.p, send_ids.data(), (size_t)total * 4, hipMemcpyHostToDevice, stream));
+    if (!rows.empty()) {
+        MHIP(m, r, hipMemcpyAsync(H.d_rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, stream));
+        MHIP(m, r, hipMemcpyAsync(H.d_src.p, src.data(), src.size() * 4, hipMemcpyHostToDevice, stream));
+    }
+    MHIP(m, r, hipStreamSynchronize(stream)); // the host vectors go away
+    return S2D_OK;
+}
+
+// After the plans of all ranks are in (behind a barrier): does anybody swap anything, and do the two sides of every
+// pair agree on how much?
+int settle_plans(s2d_multi* m, int r)
+{
+    HaloRank& H = m->halo[(size_t)r];
+    H.any_exchange = false;
+    for (int p = 0; p < m->world; p++) {
+        const HaloRank& P = m->halo[(size_t)p];
+        H.any_exchange = H.any_exchange || P.total > 0;
+        if (p != r && P.splits[(size_t)r] != H.splits[(size_t)p])
+            return rank_fail(m, r, S2D_E_STATE, "slab ownership: ranks %d and %d disagree on the rows they share (%d vs %d)", r, p,
+                             H.splits[(size_t)p], P.splits[(size_t)r]);
+    }
+    return S2D_OK;
+}
+
+// Hold sets from scratch; every context holds a complete, identical copy of the splats and the Adam state.
+int hold_fresh(s2d_multi* m, int r)
+{
+    HaloRank& H = m->halo[(size_t)r];
+    s2d_ctx* c = m->ctx[(size_t)r];
+    hipStream_t stream = (hipStream_t)s2d_stream(c);
+    const size_t n = (size_t)m->n;
+    MHIP(m, r, hipSetDevice(m->devices[(size_t)r]));
+    for (hipEvent_t& e : H.ev_sent)
+        if (!e) MHIP(m, r, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (int rc = s2d_halo_commit(c, nullptr, r, 0)) return rc; // hold everything: the masks below cover every splat
+    MHIP(m, r, H.d_mask.reserve(n));
+    H.fresh.resize(n);
+    H.mask.assign(n, 0u);
+    H.held.clear();
+    H.out_ids.assign((size_t)m->world, {});
+    H.out_mask.assign((size_t)m->world, {});
+    H.out_off.assign((size_t)m->world, 0);
+    if (int rc = s2d_halo_masks(c, m->world, m->bounds.data(), m->margin, H.d_mask.p)) return rc;
+    MHIP(m, r, hipMemcpyAsync(H.fresh.data(), H.d_mask.p, n * 4, hipMemcpyDeviceToHost, stream));
+    MHIP(m, r, hipStreamSynchronize(stream));
+    for (size_t i = 0; i < n; i++)
+        if ((H.fresh[i] >> r) & 1u) {
+            H.mask[i] = H.fresh[i];
+            H.held.push_back((int32_t)i);
+        }
+    MHIP(m, r, hipMemcpyAsync(H.d_mask.p, H.mask.data(), n * 4, hipMemcpyHostToDevice, stream));
+    if (int rc = s2d_halo_commit(c, H.d_mask.p, r, 1)) return rc;
+    if (int rc = plan(m, r)) return rc;
+    if (!meet(m)) return kStopped;
+    return settle_plans(m, r);
+}
+
+// Refresh the hold sets from the current parameters (every `interval` iterations).  A splat that has come within
+// reach + margin of a rank that does not hold it yet is handed over -- parameters and Adam moments, by its
+// lowest-ranked holder -- before it can touch that rank's rows; a holder it has left drops it.
+int refresh(s2d_multi* m, int r)
+{
+    HaloRank& H = m->halo[(size_t)r];
+    s2d_ctx* c = m->ctx[(size_t)r];
+    hipStream_t stream = (hipStream_t)s2d_stream(c);
+    const int world = m->world;
+    const size_t n = (size_t)m->n;
+    const uint32_t me = 1u << r;
+    if (int rc = s2d_synchronize(c)) return rc; // the finite guard; and every copy this rank queued has landed
+    if (int rc = s2d_halo_masks(c, world, m->bounds.data(), m->margin, H.d_mask.p)) return rc;
+    MHIP(m, r, hipMemcpyAsync(H.fresh.data(), H.d_mask.p, n * 4, hipMemcpyDeviceToHost, stream));
+    MHIP(m, r, hipStreamSynchronize(stream));
+    for (int q = 0; q < world; q++) {
+        H.out_ids[(size_t)q].clear();
+        H.out_mask[(size_t)q].clear();
+    }
+    std::vector<int32_t> keep;
+    keep.reserve(H.held.size());
+    for (const int32_t i : H.held) {
+        const uint32_t old = H.mask[(size_t)i], now = H.fresh[(size_t)i];
+        if ((old & (0u - old)) == me) { // the lowest-ranked old holder hands the splat to its new holders
+            uint32_t arriving = now & ~old;
+            while (arriving) {
+                const int q = __builtin_ctz(arriving);
+                arriving &= arriving - 1u;
+                H.out_ids[(size_t)q].push_back(i);
+                H.out_mask[(size_t)q].push_back(now);
+            }
+        }
+        if (now & me) {
+            H.mask[(size_t)i] = now;
+            keep.push_back(i);
+        } else {
+            H.mask[(size_t)i] = 0u;
+        }
+    }
+    // outgoing state rows, one segment per destination
+    std::vector<int32_t> pay_ids;
+    for (int q = 0; q < world; q++) {
+        H.out_off[(size_t)q] = (int32_t)pay_ids.size();
+        pay_ids.insert(pay_ids.end(), H.out_ids[(size_t)q].begin(), H.out_ids[(size_t)q].end());
+    }
+    const int k_out = (int)pay_ids.size();
+    if (k_out) {
+        MHIP(m, r, H.d_pay_ids.reserve((size_t)k_out));
+        MHIP(m, r, H.d_pay_sp.reserve((size_t)k_out * 9));
+        MHIP(m, r, H.d_pay_ad.reserve((size_t)k_out * 18));
+        MHIP(m, r, hipMemcpyAsync(H.d_pay_ids.p, pay_ids.data(), (size_t)k_out * 4, hipMemcpyHostToDevice, stream));
+        if (int rc = s2d_rows_gather(c, S2D_ROWS_SPLATS, H.d_pay_ids.p, k_out, H.d_pay_sp.p)) return rc;
+        if (int rc = s2d_rows_gather(c, S2D_ROWS_ADAM, H.d_pay_ids.p, k_out, H.d_pay_ad.p)) return rc;
+        MHIP(m, r, hipStreamSynchronize(stream));
+    }
+    if (!meet(m)) return kStopped; // every rank's outgoing rows are in place, every stream is idle
+    // incoming state rows, in sender order
+    std::vector<int32_t> in_ids;
+    std::vector<uint32_t> in_mask;
+    for (int p = 0; p < world; p++)
+        if (p != r) {
+            const HaloRank& P = m->halo[(size_t)p];
+            in_ids.insert(in_ids.end(), P.out_ids[(size_t)r].begin(), P.out_ids[(size_t)r].end());
+            in_mask.insert(in_mask.end(), P.out_mask[(size_t)r].begin(), P.out_mask[(size_t)r].end());
+        }
+    const int k_in = (int)in_ids.size();
+    int late = 0;
+    if (k_in) {
+        MHIP(m, r, H.d_in_ids.reserve((size_t)k_in));
+        MHIP(m, r, H.d_in_sp.reserve((size_t)k_in * 9));
+        MHIP(m, r, H.d_in_ad.reserve((size_t)k_in * 18));
+        MHIP(m, r, hipMemcpyAsync(H.d_in_ids.p, in_ids.data(), (size_t)k_in * 4, hipMemcpyHostToDevice, stream));
+        size_t off = 0;
+        for (int p = 0; p < world; p++)
+            if (p != r) {
+                const HaloRank& P = m->halo[(size_t)p];
+                const size_t cnt = P.out_ids[(size_t)r].size(), from = (size_t)P.out_off[(size_t)r];
+                if (!cnt) continue;
+                MHIP(m, r, rank_copy(m, H.d_in_sp.p + off * 9, r, P.d_pay_sp.p + from * 9, p, cnt * 9 * sizeof(float), stream));
+                MHIP(m, r, rank_copy(m, H.d_in_ad.p + off * 18, r, P.d_pay_ad.p + from * 18, p, cnt * 18 * sizeof(float), stream));
+                off += cnt;
+            }
+        std::vector<float> sp((size_t)k_in * 9);
+        MHIP(m, r, hipMemcpyAsync(sp.data(), H.d_in_sp.p, sp.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
+        MHIP(m, r, hipStreamSynchronize(stream));
+        // a splat that arrives already touching this rank's rows was rasterised here without being listed: the margin
+        // did not outlast the interval
+        const float r0 = (float)m->bounds[(size_t)r], r1 = (float)m->bounds[(size_t)r + 1];
+        for (int j = 0; j < k_in; j++) {
+            const float* q = sp.data() + (size_t)j * 9;
+            const float reach = 3.0f * std::max(q[2], q[3]) + 2.0f;
+            if (q[1] + reach >= r0 && q[1] - reach <= r1) late++;
+        }
+    }
+    if (late) m->late.fetch_add(late);
+    if (!meet(m)) return kStopped; // everybody has fetched its rows and reported late arrivals
+    if (m->late.load() > 0)        // fatal on every rank alike
+        return rank_fail(m, r, S2D_E_STATE, "slab ownership: %d splat(s) reached the rows of a rank before their state was handed "
+                                            "over (%d on rank %d): the margin of %.1f rows did not outlast %d iterations",
+                         m->late.load(), late, r, (double)m->margin, m->interval);
+    if (k_in) {
+        if (int rc = s2d_rows_scatter(c, S2D_ROWS_SPLATS, H.d_in_ids.p, k_in, H.d_in_sp.p)) return rc;
+        if (int rc = s2d_rows_scatter(c, S2D_ROWS_ADAM, H.d_in_ids.p, k_in, H.d_in_ad.p)) return rc;
+        for (int j = 0; j < k_in; j++) H.mask[(size_t)in_ids[(size_t)j]] = in_mask[(size_t)j];
+        keep.insert(keep.end(), in_ids.begin(), in_ids.end());
+        std::sort(keep.begin(), keep.end());
+    }
+    H.held.swap(keep);
+    H.handed += k_out + k_in;
+    MHIP(m, r, hipMemcpyAsync(H.d_mask.p, H.mask.data(), n * 4, hipMemcpyHostToDevice, stream));
+    if (int rc = s2d_halo_commit(c, H.d_mask.p, r, k_in > 0)) return rc; // departures alone leave the tile lists valid
+    if (int rc = plan(m, r)) return rc;
+    if (!meet(m)) return kStopped; // plans are in; the outgoing buffers may be re-used
+    return settle_plans(m, r);
+}
+
+// The iteration's exchange: the partial gradient rows of splats this rank shares go to their other holders, theirs
+// come here, and every holder adds the partials in rank order.
+int exchange_grads(s2d_multi* m, int r)
+{
+    HaloRank& H = m->halo[(size_t)r];
+    if (!H.any_exchange) return S2D_OK;
+    s2d_ctx* c = m->ctx[(size_t)r];
+    hipStream_t stream = (hipStream_t)s2d_stream(c);
+    const int b = (int)(H.seq++ & 1u);
+    if (H.total) {
+        if (int rc = s2d_rows_gather(c, S2D_ROWS_GRADS, H.d_send_ids.p, H.total, H.d_send[b].p)) return rc;
+        MHIP(m, r, hipEventRecord(H.ev_sent[b], stream));
+    }
+    if (!meet(m)) return kStopped; // every sender's event is on record: the copies below can wait for them
+    for (int p = 0; p < m->world; p++) {
+        const int cnt = H.splits[(size_t)p];
+        if (p == r || cnt == 0) continue;
+        const HaloRank& P = m->halo[(size_t)p];
+        MHIP(m, r, hipStreamWaitEvent(stream, P.ev_sent[b], 0));
+        MHIP(m, r, rank_copy(m, H.d_recv.p + (size_t)H.offsets[(size_t)p] * 9, r, P.d_send[b].p + (size_t)P.offsets[(size_t)r] * 9, p,
+                             (size_t)cnt * 9 * sizeof(float), stream));
+    }
+    if (H.n_rows)
+        if (int rc = s2d_grads_combine(c, H.d_rows.p, H.n_rows, H.d_src.p, m->world, H.d_recv.p)) return rc;
+    return S2D_OK;
+}
+
 // One rank's share of s2d_multi_step: `iters` frames of main.cpp:334 on its rows.
 int rank_step(s2d_multi* m, int rank)
 {
@@ -182,16 +545,18 @@ int rank_step(s2d_multi* m, int rank)
         const bool last = k + 1 == m->step_iters;
         rc = s2d_forward_backward(c, bwd_flags | (last ? 0u : S2D_FB_SKIP_IMAGE));
         if (rc != S2D_OK) break;
-        {
-            // the only exchange of the iteration: the sum of the slabs' partial gradients, in place (a handle on one
-            // device goes through RCCL too: same code whatever the device count)
+        // the only exchange of the iteration
+        if (m->scheme == SCHEME_OWNERSHIP) {
+            rc = exchange_grads(m, rank);
+        } else if (m->scheme == SCHEME_REPLICATED) { // (a handle on one device goes through RCCL too: same code whatever N)
             if (m->share_gpu) {
                 if (m->world > 1 && !staged_all_reduce(m, rank, grads, count, stream)) rc = S2D_E_HIP;
             } else if (m->rccl.AllReduce(grads, grads, count, ncclFloat, ncclSum, m->comms[(size_t)rank], stream) != ncclSuccess) {
-                rc = S2D_E_HIP;
+                rc = rank_fail(m, rank, S2D_E_HIP, "ncclAllReduce failed");
             }
         }
         if (rc == S2D_OK) rc = s2d_adam_step(c, m->step_flags);
+        if (rc == S2D_OK && m->scheme == SCHEME_OWNERSHIP && (m->hold_age + k + 1) % m->interval == 0) rc = refresh(m, rank);
     }
     std::vector<double>& mine = m->sqerr[(size_t)rank];
     mine.assign((size_t)m->step_iters, 0.0);
@@ -212,9 +577,17 @@ void worker_main(s2d_multi* m, int rank)
             seen = m->cmd_seq;
             cmd = m->cmd;
         }
-        if (cmd == CMD_QUIT) return;
+        if (cmd == CMD_QUIT) {
+            (void)hipSetDevice(m->devices[(size_t)rank]);
+            m->halo[(size_t)rank].release();
+            return;
+        }
         int rc = S2D_OK;
         if (cmd == CMD_STEP) rc = rank_step(m, rank);
+        if (cmd == CMD_HOLD) {
+            rc = hold_fresh(m, rank);
+            if (rc != S2D_OK) m->barrier.abort();
+        }
         {
             std::lock_guard<std::mutex> lk(m->m);
             m->rank_rc[(size_t)rank] = rc;
@@ -227,6 +600,9 @@ void worker_main(s2d_multi* m, int rank)
 // Hand `cmd` to every worker and wait for all of them.
 void run_command(s2d_multi* m, int cmd)
 {
+    for (std::string& s : m->rank_msg) s.clear();
+    m->late = 0;
+    m->barrier.reset();
     {
         std::lock_guard<std::mutex> lk(m->m);
         m->cmd = cmd;
@@ -240,10 +616,41 @@ void run_command(s2d_multi* m, int cmd)
 
 int first_failure(s2d_multi* m, const char* what)
 {
+    for (int r = 0; r < m->world; r++) {
+        const int rc = m->rank_rc[(size_t)r];
+        if (rc != S2D_OK && rc != kStopped)
+            return mfail(m, rc, "%s on rank %d (device %d): %s", what, r, m->devices[(size_t)r],
+                         m->rank_msg[(size_t)r].empty() ? s2d_last_error(m->ctx[(size_t)r]) : m->rank_msg[(size_t)r].c_str());
+    }
     for (int r = 0; r < m->world; r++)
-        if (m->rank_rc[(size_t)r] != S2D_OK)
-            return mfail(m, m->rank_rc[(size_t)r], "%s on rank %d (device %d): %s", what, r, m->devices[(size_t)r],
-                         s2d_last_error(m->ctx[(size_t)r]));
+        if (m->rank_rc[(size_t)r] != S2D_OK) return mfail(m, S2D_E_STATE, "%s: rank %d stopped without a failing rank", what, r);
+    return S2D_OK;
+}
+
+// Slab ownership: make the hold sets if the replicas were (re)filled since the last time.
+int ensure_hold(s2d_multi* m)
+{
+    if (m->scheme != SCHEME_OWNERSHIP || m->hold_valid) return S2D_OK;
+    run_command(m, CMD_HOLD);
+    if (int rc = first_failure(m, "making the hold sets")) return rc;
+    m->hold_valid = true;
+    m->hold_age = 0;
+    return S2D_OK;
+}
+
+inline bool lowest_holder(uint32_t mask, int r) { return mask != 0u && (mask & (0u - mask)) == (1u << r); }
+
+// Slab ownership: the complete parameter or Adam array, every row from its lowest-ranked holder.
+template <typename Row, typename Get>
+int assemble(s2d_multi* m, Row* out, Get get)
+{
+    std::vector<Row> tmp((size_t)m->n);
+    for (int r = 0; r < m->world; r++) {
+        if (int rc = get(m->ctx[(size_t)r], tmp.data())) return mfail(m, rc, "reading rank %d: %s", r, s2d_last_error(m->ctx[(size_t)r]));
+        const HaloRank& H = m->halo[(size_t)r];
+        for (const int32_t i : H.held)
+            if (lowest_holder(H.mask[(size_t)i], r)) out[(size_t)i] = tmp[(size_t)i];
+    }
     return S2D_OK;
 }
 
@@ -253,7 +660,7 @@ extern "C" {
 
 int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_devices, uint32_t flags, s2d_multi** out)
 {
-    if (!cfg || !out || !devices || n_devices < 1 || n_devices > 64 || cfg->struct_size != sizeof(s2d_config)) return S2D_E_INVALID;
+    if (!cfg || !out || !devices || n_devices < 1 || n_devices > 32 || cfg->struct_size != sizeof(s2d_config)) return S2D_E_INVALID;
     *out = nullptr;
     if (cfg->row_begin != 0 || cfg->row_end != 0 || cfg->stream != nullptr) return S2D_E_INVALID; // the handle cuts the slabs itself
     s2d_multi* m = new (std::nothrow) s2d_multi();
@@ -264,6 +671,7 @@ int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_de
     m->H = cfg->height;
     m->n = cfg->n_splats;
     m->share_gpu = (flags & S2D_MULTI_SHARE_GPU) != 0;
+    m->scheme = (flags & S2D_MULTI_REPLICATED) ? SCHEME_REPLICATED : (n_devices > 1 ? SCHEME_OWNERSHIP : SCHEME_NONE);
     m->devices.assign(devices, devices + n_devices);
     if (m->share_gpu)
         for (int& d : m->devices) d = devices[0];
@@ -272,20 +680,29 @@ int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_de
     m->row_begin.resize((size_t)m->world);
     m->row_end.resize((size_t)m->world);
     m->rank_rc.assign((size_t)m->world, S2D_OK);
+    m->rank_msg.resize((size_t)m->world);
     m->sqerr.resize((size_t)m->world);
+    m->halo.resize((size_t)m->world);
     m->barrier.n = m->world;
+    m->bounds.resize((size_t)m->world + 1);
     for (int r = 0; r < m->world; r++) {
         s2d_config c = *cfg;
         c.device = m->devices[(size_t)r];
         slab_rows(m->H, r, m->world, &c.row_begin, &c.row_end);
         m->row_begin[(size_t)r] = c.row_begin;
         m->row_end[(size_t)r] = c.row_end;
+        m->bounds[(size_t)r] = c.row_begin;
         const int rc = s2d_create(&c, &m->ctx[(size_t)r]);
         if (rc != S2D_OK)
             return mfail(m, rc, "s2d_create for device %d, rows %d..%d: %s", c.device, c.row_begin, c.row_end,
                          m->ctx[(size_t)r] ? s2d_last_error(m->ctx[(size_t)r]) : "rejected configuration");
     }
-    if (!m->share_gpu) {
+    m->bounds[(size_t)m->world] = m->H;
+    // Adam moves a parameter by at most lr * |m^| / sqrt(v^) <= 2.35 * lr per step for beta = (0.9, 0.99); pos.y moves by
+    // that and reach = 3 * max(sx, sy) + 2 by three times that: the margin must outlast one refresh interval
+    const float lr = cfg->training_rate > 0.0f ? cfg->training_rate : 0.05f;
+    m->margin = std::max(8.0f, 1.1f * 2.35f * 4.0f * lr * (float)m->interval);
+    if (m->scheme == SCHEME_REPLICATED && !m->share_gpu) {
         std::string why;
         if (!load_rccl(&m->rccl, &why)) return mfail(m, S2D_E_HIP, "%s", why.c_str());
         m->comms.assign((size_t)m->world, nullptr);
@@ -295,12 +712,28 @@ int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_de
             return mfail(m, S2D_E_HIP, "ncclCommInitAll over %d devices: %s (RCCL takes one rank per GPU; S2D_MULTI_SHARE_GPU rehearses "
                                        "on fewer)", m->world, m->rccl.GetErrorString(nrc));
         }
-    } else if (m->world > 1) {
+    } else if (m->scheme == SCHEME_REPLICATED && m->world > 1) {
         m->host_grads.assign((size_t)m->world, nullptr);
         if (hipSetDevice(m->devices[0]) != hipSuccess) return mfail(m, S2D_E_HIP, "hipSetDevice(%d)", m->devices[0]);
         for (int r = 0; r < m->world; r++)
             if (hipHostMalloc((void**)&m->host_grads[(size_t)r], (size_t)m->n * 9 * sizeof(float) + 16, hipHostMallocDefault) != hipSuccess)
                 return mfail(m, S2D_E_NOMEM, "host staging buffers for %d ranks", m->world);
+    } else if (m->scheme == SCHEME_OWNERSHIP) {
+        // one rank per GPU, and direct peer-to-peer copies where the fabric allows them (the copies work without, staged)
+        for (int a = 0; a < m->world; a++)
+            for (int b = 0; b < m->world; b++) {
+                const int da = m->devices[(size_t)a], db = m->devices[(size_t)b];
+                if (a == b || da == db) {
+                    if (a != b && !m->share_gpu) return mfail(m, S2D_E_INVALID, "device %d listed twice (S2D_MULTI_SHARE_GPU rehearses several ranks on one GPU)", da);
+                    continue;
+                }
+                int can = 0;
+                if (hipSetDevice(da) != hipSuccess) return mfail(m, S2D_E_HIP, "hipSetDevice(%d)", da);
+                if (hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) {
+                    const hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError(); // copies are staged then
+                }
+            }
     }
     for (int r = 0; r < m->world; r++) m->workers.emplace_back(worker_main, m, r);
     return S2D_OK;
@@ -330,6 +763,22 @@ void s2d_multi_destroy(s2d_multi* m)
 const char* s2d_multi_last_error(const s2d_multi* m) { return m ? m->err : "null handle"; }
 
 int s2d_multi_device_count(const s2d_multi* m) { return m ? m->world : 0; }
+
+int s2d_multi_exchange_info(s2d_multi* m, int64_t* out4)
+{
+    if (!m || !out4) return S2D_E_INVALID;
+    out4[0] = m->scheme;
+    out4[1] = out4[2] = out4[3] = 0;
+    if (m->scheme == SCHEME_OWNERSHIP && m->hold_valid)
+        for (const HaloRank& H : m->halo) {
+            out4[1] += H.total;
+            out4[2] += H.handed;
+            out4[3] += (int64_t)H.held.size();
+        }
+    else
+        out4[3] = (int64_t)m->n * m->world;
+    return S2D_OK;
+}
 
 // The calls below address every replica in turn from the caller's thread (the workers are idle between commands).
 #define S2D_EACH(m, what, call)                                                                                      \
@@ -361,19 +810,43 @@ int s2d_multi_init_splats(s2d_multi* m)
     if (!m) return S2D_E_INVALID;
     S2D_EACH(m, "s2d_init_splats", s2d_init_splats(c)); // every replica: the same deterministic init(), main.cpp:280-305
     m->iterations = 0;
+    m->hold_valid = false; // every replica is complete again: new hold sets at the next step
+    return S2D_OK;
+}
+
+int s2d_multi_get_adam(s2d_multi* m, s2d_splat_adam* adams, float* beta1t, float* beta2t, int32_t* iterations)
+{
+    if (!m) return S2D_E_INVALID;
+    if (m->scheme == SCHEME_OWNERSHIP && m->hold_valid && adams) {
+        if (int rc = assemble(m, adams, [](s2d_ctx* c, s2d_splat_adam* p) { return s2d_get_adam(c, p, nullptr, nullptr, nullptr); })) return rc;
+        adams = nullptr;
+    }
+    if (int rc = s2d_get_adam(m->ctx[0], adams, beta1t, beta2t, iterations)) return mfail(m, rc, "s2d_get_adam: %s", s2d_last_error(m->ctx[0]));
     return S2D_OK;
 }
 
 int s2d_multi_set_splats(s2d_multi* m, const s2d_splat* splats)
 {
     if (!m || (!splats && m->n)) return S2D_E_INVALID;
+    if (m->scheme == SCHEME_OWNERSHIP && m->hold_valid) {
+        // the replicas are about to hold everything again: complete their Adam state first (a rank has current
+        // moments only for the splats it holds)
+        std::vector<s2d_splat_adam> full((size_t)m->n);
+        float b1 = 0.f, b2 = 0.f;
+        int32_t it = 0;
+        if (int rc = s2d_multi_get_adam(m, full.data(), &b1, &b2, &it)) return rc;
+        S2D_EACH(m, "s2d_set_adam", s2d_set_adam(c, full.data(), b1, b2, it));
+    }
     S2D_EACH(m, "s2d_set_splats", s2d_set_splats(c, splats));
+    m->hold_valid = false;
     return S2D_OK;
 }
 
 int s2d_multi_get_splats(s2d_multi* m, s2d_splat* splats)
 {
     if (!m || (!splats && m->n)) return S2D_E_INVALID;
+    if (m->scheme == SCHEME_OWNERSHIP && m->hold_valid)
+        return assemble(m, splats, [](s2d_ctx* c, s2d_splat* p) { return s2d_get_splats(c, p); });
     if (int rc = s2d_get_splats(m->ctx[0], splats)) return mfail(m, rc, "s2d_get_splats: %s", s2d_last_error(m->ctx[0]));
     return S2D_OK; // the replicas are bit-identical: any one of them
 }
@@ -381,25 +854,18 @@ int s2d_multi_get_splats(s2d_multi* m, s2d_splat* splats)
 int s2d_multi_set_adam(s2d_multi* m, const s2d_splat_adam* adams, float beta1t, float beta2t, int32_t iterations)
 {
     if (!m || (!adams && m->n) || iterations < 0) return S2D_E_INVALID;
-    S2D_EACH(m, "s2d_set_adam", s2d_set_adam(c, adams, beta1t, beta2t, iterations));
+    S2D_EACH(m, "s2d_set_adam", s2d_set_adam(c, adams, beta1t, beta2t, iterations)); // complete on every rank; hold sets unaffected
     m->iterations = iterations;
-    return S2D_OK;
-}
-
-int s2d_multi_get_adam(s2d_multi* m, s2d_splat_adam* adams, float* beta1t, float* beta2t, int32_t* iterations)
-{
-    if (!m) return S2D_E_INVALID;
-    if (int rc = s2d_get_adam(m->ctx[0], adams, beta1t, beta2t, iterations)) return mfail(m, rc, "s2d_get_adam: %s", s2d_last_error(m->ctx[0]));
     return S2D_OK;
 }
 
 int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out)
 {
     if (!m || iters < 0 || iters > (1 << 16)) return S2D_E_INVALID;
+    if (int rc = ensure_hold(m)) return rc;
     m->step_iters = iters;
     m->step_flags = flags;
     m->step_first_iter = m->iterations;
-    m->barrier.reset();
     run_command(m, CMD_STEP);
     if (int rc = first_failure(m, "s2d_multi_step")) {
         int32_t it = 0; // where the replicas stand now (a non-finite stop winds the counters back, s2d_api.hip)
@@ -407,6 +873,7 @@ int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out)
         return rc;
     }
     m->iterations += iters;
+    m->hold_age += iters;
     if (mse_out) {
         const double norm = (double)((long long)m->H * m->W * 3);
         for (int k = 0; k < iters; k++) {

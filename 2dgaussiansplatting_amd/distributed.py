@@ -181,7 +181,8 @@ def _all_to_all_rows(dist, recv, send, recv_rows, send_rows):
 
 def all_to_all_selftest(dist, device):
     """The collective pattern HaloStep relies on, on tiny tensors: all_to_all_single with UNEVEN row counts, zero-size
-    segments for non-neighbours, float32 and int32 payloads, plus the equal-split int64 count exchange.  Returns the
+    segments for non-neighbours, float32 and int32 payloads, an exchange in which nobody sends anything, plus the
+    equal-split int64 count exchange.  Returns the
     same verdict on every rank (an all-reduce of the local results), so callers can fall back together."""
     import torch
     ok = 1
@@ -196,6 +197,10 @@ def all_to_all_selftest(dist, device):
             _all_to_all_rows(dist, recv, send, recv_rows, send_rows)
             want = torch.cat([torch.full((k, 9), p * 100 + r, dtype=dtype, device=device) for p, k in enumerate(recv_rows)])
             ok &= int(torch.equal(recv, want))
+        # a refresh in which no splat changes hands: nothing to send or receive on any rank (zero-size tensors)
+        none = [0] * w
+        _all_to_all_rows(dist, torch.empty((0, 29), dtype=torch.int32, device=device),
+                         torch.empty((0, 29), dtype=torch.int32, device=device), none, none)
         cnt_out = torch.arange(w, dtype=torch.int64) + 10 * r
         cnt_in = torch.empty_like(cnt_out)
         if dist.get_backend() == "gloo":

@@ -48,7 +48,8 @@ struct Options {
     int device = 0;
     int rebin_interval = 0;
     int gpus = 1;               // --gpus N: devices device .. device + N - 1, one row slab each, RCCL all-reduce of the gradients
-    bool share_gpu = false;     // --share-gpu: all N ranks on --device, gradients summed through host memory instead of RCCL
+    bool share_gpu = false;     // --share-gpu: all N ranks on --device (rehearsal on a box with fewer GPUs than ranks)
+    bool replicated = false;    // --exchange dense: replicated state + RCCL all-reduce of all gradients (default: slab ownership)
                                 // (RCCL takes one rank per GPU): a rehearsal of the N-rank host logic on a box with fewer GPUs
 };
 
@@ -68,7 +69,7 @@ int usage()
                  "                     [--overlay file [--overlay-scale S] [--overlay-stride K]]\n"
                  "       splat2d_train --convert in.(s2di|ppm|png|jpg) out.(s2di|ppm|png)\n"
                  "                     [--load-checkpoint file] [--save-checkpoint file]\n"
-                 "                     [--device D] [--gpus N [--share-gpu]] [--rebin-interval R] [--quiet]\n");
+                 "                     [--device D] [--gpus N [--exchange halo|dense] [--share-gpu]] [--rebin-interval R] [--quiet]\n");
     return 2;
 }
 
@@ -104,7 +105,8 @@ int run_multi(const Options& o, int W, int H, const std::vector<float>& imageRef
             return rc_ == S2D_E_NONFINITE ? 3 : 1; /* the reference abort()s */           \
         }                                                                                 \
     } while (0)
-    CKM(s2d_multi_create(&cfg, devs.data(), o.gpus, o.share_gpu ? S2D_MULTI_SHARE_GPU : 0u, &m));
+    CKM(s2d_multi_create(&cfg, devs.data(), o.gpus,
+                         (o.share_gpu ? S2D_MULTI_SHARE_GPU : 0u) | (o.replicated ? S2D_MULTI_REPLICATED : 0u), &m));
     if (imageRef.empty()) CKM(s2d_multi_set_target_synthetic(m));
     else CKM(s2d_multi_set_target(m, imageRef.data()));
     CKM(s2d_multi_init_splats(m)); // init(); main.cpp:307
@@ -120,9 +122,18 @@ int run_multi(const Options& o, int W, int H, const std::vector<float>& imageRef
         iterations += k;
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats, %d ranks: row slabs + %s of the gradients)\n",
-                 o.iters, secs, secs > 0 ? o.iters / secs : 0.0, W, H, o.n_splats, o.gpus,
-                 o.share_gpu ? "host-staged sum (ranks share one GPU)" : "RCCL all-reduce");
+    int64_t info[4] = {0, 0, 0, 0};
+    CKM(s2d_multi_exchange_info(m, info));
+    char how[200];
+    if (info[0] == 2)
+        std::snprintf(how, sizeof(how), "replicated state, %s of all gradients", o.share_gpu ? "host-staged sum (ranks share one GPU)" : "RCCL all-reduce");
+    else if (info[0] == 1)
+        std::snprintf(how, sizeof(how), "slab ownership, %lld gradient rows swapped per iteration by %s, %lld state rows handed over",
+                      (long long)info[1], o.share_gpu ? "device copies (ranks share one GPU)" : "peer-to-peer copies", (long long)info[2]);
+    else
+        std::snprintf(how, sizeof(how), "one device, nothing to exchange");
+    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats, %d ranks: row slabs; %s)\n", o.iters, secs,
+                 secs > 0 ? o.iters / secs : 0.0, W, H, o.n_splats, o.gpus, how);
 #undef CKM
     s2d_multi_destroy(m);
     return 0;
@@ -157,6 +168,11 @@ int main(int argc, char** argv)
         else if (a == "--device") o.device = std::atoi(next("--device"));
         else if (a == "--gpus") o.gpus = std::atoi(next("--gpus"));
         else if (a == "--share-gpu") o.share_gpu = true;
+        else if (a == "--exchange") {
+            const std::string v = next("--exchange");
+            if (v != "halo" && v != "dense") return usage();
+            o.replicated = v == "dense";
+        }
         else if (a == "--rebin-interval") o.rebin_interval = std::atoi(next("--rebin-interval"));
         else if (a == "--quiet") o.quiet = true;
         else return usage();

@@ -203,7 +203,8 @@ int s2d_get_mse(s2d_ctx* ctx, double* mse);
 int s2d_halo_masks(s2d_ctx* ctx, int32_t world, const int32_t* row_bounds, float margin_rows, uint32_t* masks_device);
 /* This context holds exactly the splats with bit `rank` set.  added != 0: splats this context did not hold before
  * are among them (their rows were written with s2d_rows_scatter): the tile lists are rebuilt before the next
- * forward.  Splats that merely left keep their (now empty) list entries until the next regular rebuild. */
+ * forward.  Splats that merely left keep their (now empty) list entries until the next regular rebuild.
+ * masks_device == NULL: the context holds every splat again (its copy of all rows must be current). */
 int s2d_halo_commit(s2d_ctx* ctx, const uint32_t* masks_device, int32_t rank, int32_t added);
 /* out[j] = row ids[j] of the chosen array / row ids[j] = in[j] (ids distinct; out-of-range ids read 0 / are skipped) */
 int s2d_rows_gather(s2d_ctx* ctx, int32_t what, const int32_t* ids_device, int32_t count, float* out_device);
@@ -231,14 +232,23 @@ int s2d_synchronize(s2d_ctx* ctx);
 
 /* ---- several GPUs behind one handle ("device list ...; multi-GPU fan-out is internal") -------------
  * s2d_multi keeps the single-threaded call pattern of main.cpp:334 and runs it on n_devices GPUs: the image is cut into
- * n_devices row slabs (whole 16-pixel tile rows), every device gets an ordinary context for its slab with splats and Adam
- * state replicated, and per iteration every device rasterises its rows forward and backward, the N x 9 fp32 gradient
- * arrays are summed in place by an RCCL all-reduce over xGMI (on each context's stream, between s2d_forward_backward and
- * s2d_adam_step), and every device applies the identical Adam step.  One worker thread per device inside; the caller
- * needs none.  cfg: as for s2d_create, with device / row_begin / row_end / stream unused (must be 0).  RCCL is loaded
- * (dlopen) when the first handle with more than one device is created. */
-#define S2D_MULTI_SHARE_GPU 0x1u /* rehearsal on a box with fewer GPUs than ranks (RCCL takes one rank per GPU): all ranks on
-                                  * devices[0], the gradient sum staged through pinned host memory in rank order */
+ * n_devices row slabs (whole 16-pixel tile rows), every device gets an ordinary context for its slab and a worker thread
+ * inside the library; the caller needs none.  cfg: as for s2d_create, with device / row_begin / row_end / stream unused
+ * (must be 0).  Keeping the devices consistent:
+ *  - default, slab ownership: a device holds and updates only the splats that can reach its rows; per iteration the
+ *    holders of a shared splat swap its partial gradient rows by peer-to-peer copies (xGMI) and add them in rank order;
+ *    every 64 iterations the hold sets follow the parameters and the state of a splat entering a neighbour's reach is
+ *    handed over.  get_splats / get_adam assemble the arrays from the holders.
+ *  - S2D_MULTI_REPLICATED (north_star's scheme): splats and Adam state on every device, the N x 9 fp32 gradient arrays
+ *    summed in place by an RCCL all-reduce (on each context's stream, between s2d_forward_backward and s2d_adam_step),
+ *    the identical Adam step everywhere.  RCCL is loaded (dlopen) when such a handle is created.
+ * With deterministic gradients (S2D_CFG_DETERMINISTIC) and sums formed in rank order the two give the same bits.
+ * After a failed s2d_multi_step (S2D_E_NONFINITE: the reference abort()s there) the state is for inspection only;
+ * s2d_multi_init_splats, or s2d_multi_set_splats + s2d_multi_set_adam, make the handle usable again. */
+#define S2D_MULTI_SHARE_GPU 0x1u  /* rehearsal on a box with fewer GPUs than ranks: all ranks on devices[0]; peer copies
+                                   * become device copies, the all-reduce is staged through pinned host memory in rank
+                                   * order (RCCL takes one rank per GPU) */
+#define S2D_MULTI_REPLICATED 0x2u /* replicated state + all-reduce of all gradients instead of slab ownership */
 typedef struct s2d_multi s2d_multi;
 int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_devices, uint32_t flags, s2d_multi** out);
 void s2d_multi_destroy(s2d_multi* m);
@@ -248,7 +258,7 @@ int s2d_multi_set_target(s2d_multi* m, const float* rgba32f);         /* imageRe
 int s2d_multi_set_target_synthetic(s2d_multi* m);
 int s2d_multi_init_splats(s2d_multi* m);                              /* init(), main.cpp:280-305, on every replica */
 int s2d_multi_set_splats(s2d_multi* m, const s2d_splat* splats);
-int s2d_multi_get_splats(s2d_multi* m, s2d_splat* splats);            /* the replicas are bit-identical: replica 0's */
+int s2d_multi_get_splats(s2d_multi* m, s2d_splat* splats);            /* every row from its lowest-ranked holder */
 int s2d_multi_set_adam(s2d_multi* m, const s2d_splat_adam* adams, float beta1t, float beta2t, int32_t iterations);
 int s2d_multi_get_adam(s2d_multi* m, s2d_splat_adam* adams, float* beta1t, float* beta2t, int32_t* iterations);
 /* `iters` whole iterations (main.cpp:414-809) on all devices; mse_out as for s2d_step (the slabs' squared errors are
@@ -256,6 +266,9 @@ int s2d_multi_get_adam(s2d_multi* m, s2d_splat_adam* adams, float* beta1t, float
 int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out);
 /* image0 of the last iteration of the last s2d_multi_step, assembled from the slabs. */
 int s2d_multi_get_image(s2d_multi* m, float* rgba32f);
+/* out4: scheme in use (0 none: one device, 1 slab ownership, 2 replicated), gradient rows swapped per iteration (all
+ * ranks), state rows handed over so far, splats held summed over the ranks (n_splats * n_devices when replicated). */
+int s2d_multi_exchange_info(s2d_multi* m, int64_t* out4);
 
 int s2d_get_stats(s2d_ctx* ctx, s2d_stats* out);
 /* s2d_stats.rebins without the device round trip s2d_get_stats makes (a host-side counter; never synchronises). */

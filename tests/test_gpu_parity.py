@@ -1052,9 +1052,10 @@ def test_step_leaves_the_image_of_its_last_iteration():
 
 
 def test_cpp_host_multi_gpu_path_through_rccl_on_one_gpu():
-    """host/splat2d_train.cpp --gpus N drives a multi-device handle (s2d_multi_*): one worker thread + one context per
-    GPU, ncclAllReduce of the N x 9 gradients between s2d_forward_backward and s2d_adam_step.  This box has one GPU
-    (RCCL takes one rank per GPU), so the test sends --gpus 1 through that same code (S2D_TRAIN_FORCE_MULTI): RCCL
+    """host/splat2d_train.cpp --gpus N --exchange dense drives a multi-device handle (s2d_multi_*) in its replicated-state
+    scheme: one worker thread + one context per GPU, ncclAllReduce of the N x 9 gradients between s2d_forward_backward
+    and s2d_adam_step.  This box has one GPU (RCCL takes one rank per GPU), so the test sends --gpus 1 through that
+    same code (S2D_TRAIN_FORCE_MULTI): RCCL
     loaded with dlopen, communicator set-up, the in-place all-reduce on the context's stream, the sum of the slabs'
     squared errors and the reference's trace line."""
     import subprocess
@@ -1062,15 +1063,16 @@ def test_cpp_host_multi_gpu_path_through_rccl_on_one_gpu():
     args = [exe, "--image", MINI, "--splats", "1024", "--iters", "12", "--batch", "4"]
     want = subprocess.run(args, capture_output=True, text=True, check=True).stdout.strip().splitlines()
     env = dict(os.environ, S2D_TRAIN_FORCE_MULTI="1")
-    p = subprocess.run(args + ["--gpus", "1"], capture_output=True, text=True, env=env, timeout=300)
+    p = subprocess.run(args + ["--gpus", "1", "--exchange", "dense"], capture_output=True, text=True, env=env, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     got = [ln for ln in p.stdout.strip().splitlines() if " itr, mse " in ln]
     assert got[0] == "0 itr, mse 5934.9042" and len(got) == 12
     np.testing.assert_allclose([float(l.split("mse")[1]) for l in got], [float(l.split("mse")[1]) for l in want], rtol=2e-5)
     assert "RCCL all-reduce" in p.stderr
-    # more ranks than this box has GPUs: a clean error, not a crash
-    p = subprocess.run(args + ["--gpus", "2"], capture_output=True, text=True, timeout=300)
-    assert p.returncode != 0 and p.stdout.strip() == ""
+    # more ranks than this box has GPUs: a clean error, not a crash (either scheme)
+    for extra in ([], ["--exchange", "dense"]):
+        p = subprocess.run(args + ["--gpus", "2"] + extra, capture_output=True, text=True, timeout=300)
+        assert p.returncode != 0 and p.stdout.strip() == ""
 
 
 def test_forward_backward_skip_image_flag():
@@ -1091,30 +1093,32 @@ def test_forward_backward_skip_image_flag():
     t.close(); t2.close()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_cpp_host_n_ranks_sharing_the_gpu(world):
-    """splat2d_train --gpus N --share-gpu: the N-rank host logic of the C++ loop (one thread + one slab context per rank,
-    gradient sum between s2d_forward_backward and s2d_adam_step, host-side sum of the slabs' squared errors) on a box
-    with one GPU -- the sum goes through host memory because RCCL takes one rank per GPU.  The trace must follow the
-    single-context one (only the fp32 order of the gradient sums differs)."""
+@pytest.mark.parametrize("world,exchange", [(2, "halo"), (3, "halo"), (2, "dense"), (3, "dense")])
+def test_cpp_host_n_ranks_sharing_the_gpu(world, exchange):
+    """splat2d_train --gpus N --share-gpu: the N-rank logic of the multi-device handle under the C++ loop (one thread +
+    one slab context per rank, the exchange between s2d_forward_backward and s2d_adam_step -- gradient rows of shared
+    splats between their holders, or the sum of all gradients --, the sum of the slabs' squared errors) on a box with
+    one GPU.  The trace must follow the single-context one (only the fp32 order of the gradient sums differs)."""
     import subprocess
     exe = os.path.join(os.path.dirname(S2D.__file__), "lib", "splat2d_train")
     args = [exe, "--image", MINI, "--splats", "1024", "--iters", "12", "--batch", "3"]
     want = subprocess.run(args, capture_output=True, text=True, check=True).stdout.strip().splitlines()
-    p = subprocess.run(args + ["--gpus", str(world), "--share-gpu"], capture_output=True, text=True, timeout=300)
+    p = subprocess.run(args + ["--gpus", str(world), "--share-gpu", "--exchange", exchange], capture_output=True, text=True,
+                       timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     got = [ln for ln in p.stdout.strip().splitlines() if " itr, mse " in ln]
     assert len(got) == 12 and got[0] == "0 itr, mse 5934.9042"
     np.testing.assert_allclose([float(l.split("mse")[1]) for l in got], [float(l.split("mse")[1]) for l in want], rtol=2e-5)
     assert "%d ranks" % world in p.stderr
+    assert ("slab ownership" if exchange == "halo" else "replicated state") in p.stderr
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_multi_device_handle_ranks_sharing_the_gpu(world):
+@pytest.mark.parametrize("world,replicated", [(2, False), (3, False), (2, True), (3, True)])
+def test_multi_device_handle_ranks_sharing_the_gpu(world, replicated):
     """s2d_multi_* (several GPUs behind one handle: the fan-out SURVEY.md section 8b asks for) with all ranks on this
-    box's one GPU (S2D_MULTI_SHARE_GPU: host-staged gradient sum): the first frame is bit-identical to the single
-    context's (same init(), same rows), the trace follows it (only the fp32 order of the gradient sums differs), the
-    replicas' state comes back through the handle, and a deterministic handle reproduces itself bit for bit."""
+    box's one GPU (S2D_MULTI_SHARE_GPU), in both schemes: the first frame is bit-identical to the single context's
+    (same init(), same rows), the trace follows it (only the fp32 order of the gradient sums differs), the state comes
+    back through the handle, and a deterministic handle reproduces itself bit for bit."""
     tgt = mini_target()
     with S2D.Trainer(268, 213, 1500) as t:
         t.set_target(tgt)
@@ -1125,7 +1129,7 @@ def test_multi_device_handle_ranks_sharing_the_gpu(world):
         want_splats = t.get_splats().view(np.float32)
     res = []
     for rep in range(2):
-        with S2D.MultiTrainer(268, 213, 1500, [0] * world, share_gpu=True, deterministic=True) as m:
+        with S2D.MultiTrainer(268, 213, 1500, [0] * world, share_gpu=True, deterministic=True, replicated=replicated) as m:
             m.set_target(tgt)
             m.init()
             got0 = m.step(1)
@@ -1133,20 +1137,54 @@ def test_multi_device_handle_ranks_sharing_the_gpu(world):
             got = np.concatenate([got0, m.step(4), m.step(5)])
             sp = m.get_splats()
             ad, b1, b2, it = m.get_adam()
+            info = m.exchange_info()
             res.append((got.tobytes(), sp.tobytes(), ad.tobytes()))
         assert it == 10
+        assert info["scheme"] == ("replicated" if replicated else "ownership")
+        if not replicated:   # shared splats exist, and no rank holds everything
+            assert info["rows_per_iteration"] > 0 and 1500 < info["held"] < 1500 * world
         assert img.tobytes() == want_img.tobytes()
         assert abs(got[0] - want[0]) <= 1e-12 * want[0]
         np.testing.assert_allclose(got, want, rtol=2e-5)
         np.testing.assert_allclose(sp.view(np.float32), want_splats, rtol=1e-3, atol=1e-3)
     assert res[0] == res[1]
     with pytest.raises(S2D.S2DError):
-        S2D.MultiTrainer(268, 213, 100, [0, 0])   # two ranks on one GPU without the rehearsal flag: RCCL refuses
+        S2D.MultiTrainer(268, 213, 100, [0, 0], replicated=replicated)   # two ranks on one GPU without the rehearsal flag
 
 
-def test_multi_device_handle_reports_nonfinite_like_the_single_context():
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_device_handle_ownership_equals_replicated_state_bit_for_bit(world):
+    """The handle's two schemes form the same additions when gradients are deterministic and sums go in rank order
+    (slab ownership: s2d_grads_combine; replicated state on a shared GPU: the host-staged sum), so whole runs are
+    bit-identical: MSE trace, parameters and Adam moments after 150 iterations on a scene where splats change hands at
+    the refreshes (every 64 iterations), and after a further stretch that follows a set_splats of the gathered state
+    (hold sets made afresh from complete replicas)."""
+    out = {}
+    for replicated in (False, True):
+        with S2D.MultiTrainer(768, 1024, 40000, [0] * world, share_gpu=True, deterministic=True, replicated=replicated) as m:
+            m.set_target_synthetic()
+            m.init()
+            tr = np.concatenate([m.step(50), m.step(100)])
+            info = m.exchange_info()
+            sp = m.get_splats()
+            ad, b1, b2, it = m.get_adam()
+            m.set_splats(sp)              # same values: the run must go on as if nothing had happened
+            tr2 = m.step(30)
+            sp2 = m.get_splats()
+            ad2 = m.get_adam()[0]
+            out[replicated] = (tr.tobytes(), sp.tobytes(), ad.tobytes(), tr2.tobytes(), sp2.tobytes(), ad2.tobytes())
+            if not replicated:
+                assert info["state_handovers"] > 0 and info["held"] < 40000 * world, info
+            assert it == 150 and np.isfinite(tr).all() and tr[-1] < tr[0]
+    names = ["trace", "splats", "adam", "trace after set_splats", "splats after", "adam after"]
+    for k, name in enumerate(names):
+        assert out[False][k] == out[True][k], name
+
+
+@pytest.mark.parametrize("replicated", [False, True])
+def test_multi_device_handle_reports_nonfinite_like_the_single_context(replicated):
     tgt = mini_target()
-    with S2D.MultiTrainer(268, 213, 300, [0, 0], share_gpu=True) as m:
+    with S2D.MultiTrainer(268, 213, 300, [0, 0], share_gpu=True, replicated=replicated) as m:
         m.set_target(tgt)
         m.init()
         m.step(2)
@@ -1156,3 +1194,5 @@ def test_multi_device_handle_reports_nonfinite_like_the_single_context():
         with pytest.raises(S2D.S2DError) as ei:
             m.step(3)
         assert ei.value.code == 3
+        m.init()                      # usable again after a restart
+        assert np.isfinite(m.step(2)).all()
