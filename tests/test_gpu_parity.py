@@ -836,6 +836,7 @@ def _run_ranks(world, W, H, n, steps, make_step, tgt=None):
     from thread_dist import ThreadDist
     D = importlib.import_module("2dgaussiansplatting_amd.distributed")
     res = [None] * world
+    torch.cuda.init()   # torch's lazy device initialisation, here rather than by several rank threads at once
 
     def body(rank, dist):
         r0, r1 = D.slab_rows(H, rank, world)
