@@ -102,6 +102,30 @@ def test_no_device_is_a_loud_error_not_a_fallback(lib):
     train = S2D._build.build_host_program()
     r = subprocess.run([train, "--synthetic", "32x32", "--splats", "4", "--iters", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "no CPU fallback" in r.stderr
+    # the multi-device handle: the same loud error, in both schemes, and bad arguments are rejected before any device call
+    for replicated in (False, True):
+        with pytest.raises(S2D.S2DError) as ei:
+            S2D.MultiTrainer(64, 64, 10, [0, 1], replicated=replicated)
+        assert ei.value.code == 2 and "no CPU fallback" in str(ei.value)
+    r = subprocess.run([train, "--synthetic", "32x32", "--splats", "4", "--iters", "1", "--gpus", "2"], capture_output=True, text=True)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def test_multi_handle_rejects_bad_arguments(lib):
+    import ctypes as C
+    cfg = S2D._Config()
+    cfg.struct_size = C.sizeof(S2D._Config)
+    cfg.width, cfg.height, cfg.n_splats = 64, 64, 10
+    h = C.c_void_p()
+    devs = (C.c_int32 * 2)(0, 1)
+    assert lib.s2d_multi_create(C.byref(cfg), devs, 0, 0, C.byref(h)) == 1        # no devices
+    assert lib.s2d_multi_create(C.byref(cfg), devs, 33, 0, C.byref(h)) == 1       # more ranks than hold-set bits
+    assert lib.s2d_multi_create(C.byref(cfg), None, 2, 0, C.byref(h)) == 1
+    cfg.row_begin, cfg.row_end = 0, 16                                             # the handle cuts the slabs itself
+    assert lib.s2d_multi_create(C.byref(cfg), devs, 2, 0, C.byref(h)) == 1
+    assert lib.s2d_multi_step(None, 1, 0, None) == 1 and lib.s2d_multi_device_count(None) == 0
+    assert lib.s2d_multi_last_error(None) == b"null handle"
+    lib.s2d_multi_destroy(None)
 
 
 def test_product_sources_do_not_reference_the_oracle():
