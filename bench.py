@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--height", type=int, default=4096)
     ap.add_argument("--splats", type=int, default=1_000_000)
     ap.add_argument("--rebin-interval", type=int, default=0)
+    ap.add_argument("--fp16-images", action="store_true",
+                    help="BASELINE configs[4] 'fp16 colour / fp32 grads': framebuffer and target held as 4 x fp16 per pixel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--exchange", default="halo", choices=["halo", "dense"],
@@ -189,7 +191,7 @@ def main():
     assert stream.cuda_stream != 0
     grads = torch.zeros(n * 9, dtype=torch.float32, device="cuda")
     t = S2D.Trainer(W, H, n, device=device, row_begin=r0, row_end=r1,
-                    rebin_interval=args.rebin_interval, stream=stream.cuda_stream)
+                    rebin_interval=args.rebin_interval, fp16_images=args.fp16_images, stream=stream.cuda_stream)
     t.bind_grads(grads.data_ptr())
     t.lean_backward = True  # optimizeOpacity is off (main.cpp:317): Adam never reads dSplats.opacity (main.cpp:735)
     t.set_target_synthetic()
@@ -276,14 +278,14 @@ def main():
         # the framebuffer (16 B), the backward part reads it (16 B) and the target (16 B); per splat the parameters are
         # read once per pass (2 x 36 B) and the 9 gradient floats written once (36 B).  (The events also span the
         # ~6 us squared-error reduction queued behind it.)
-        bwd_bytes = 48.0 * W * (r1 - r0) + 108.0 * n
+        bwd_bytes = (24.0 if args.fp16_images else 48.0) * W * (r1 - r0) + 108.0 * n  # fp16 images: 8 B per pixel access
         bwd_s = float(bwd_ms.item()) * 1e-3
         achieved = bwd_bytes / bwd_s / 1e9 if bwd_s > 0 else 0.0
         # HBM traffic of that kernel from the PMC counters: a RECORDED figure (rocprofv3 cannot run inside this
         # process), valid only for the kernel build and the launch it was measured on -- dropped otherwise
         traffic, traffic_note = None, "no PMC pass recorded for this build / launch"
         tp = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tp) and world == 1 and (W, H, n) == (4096, 4096, 1000000):
+        if os.path.exists(tp) and world == 1 and (W, H, n) == (4096, 4096, 1000000) and not args.fp16_images:
             try:
                 tj = json.load(open(tp))
                 if tj.get("kernel_source_digest") == kernel_source_digest():
@@ -298,7 +300,7 @@ def main():
         rp = os.path.join(ROOT, "tests", "golden", "bench_reference_trace.json")
         if os.path.exists(rp):
             rj = json.load(open(rp))
-            if (rj["width"], rj["height"], rj["n_splats"]) == (W, H, n) and 0 <= psnr_iter < len(rj["mse"]):
+            if (rj["width"], rj["height"], rj["n_splats"]) == (W, H, n) and 0 <= psnr_iter < len(rj["mse"]) and not args.fp16_images:
                 psnr_ref = 10.0 * float(np.log10(255.0 ** 2 / rj["mse"][psnr_iter]))
         psnr_gpu = (10.0 * float(np.log10(255.0 ** 2 / (float(sq200[0].item()) / (H * W * 3)))) if sq200 is not None and float(sq200[0].item()) > 0 else None)
         steady = step_ms[~rebuilds] if (~rebuilds).any() else step_ms
@@ -320,7 +322,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic target ref(x,y)=(x/W,1-x/W,y/H); splats from the reference's init() seeds",
-            "config": {"workload": "%dx%d synthetic RGB, %d Gaussians, fp32%s" % (W, H, n, " (BASELINE.json configs[3])" if (W, H, n) == (4096, 4096, 1000000) else ""),
+            "config": {"workload": "%dx%d synthetic RGB, %d Gaussians, %s%s" % (
+                           W, H, n, "fp16 colour / fp32 gradients" if args.fp16_images else "fp32",
+                           " (BASELINE.json configs[3])" if (W, H, n, args.fp16_images) == (4096, 4096, 1000000, False) else
+                           " (BASELINE.json configs[4])" if (W, H, n, args.fp16_images) == (8192, 8192, 4000000, True) else ""),
                        "width": W, "height": H, "n_splats": n,
                        "parallelism": "rowslab%d%s" % (world, ("+%s-%s" % ("rccl" if args.backend == "nccl" else args.backend,
                                                                               "halo-exchange" if exchange == "halo" else "allreduce-grads")) if use_dist else ""),
@@ -350,7 +355,7 @@ def main():
             # kernels in one extra untimed iteration, x 30 flop (forward, main.cpp:523-533) + 110 flop (backward,
             # main.cpp:607-709) per pair, against the 157.3 TFLOP/s fp32 vector peak.
             sp = t.get_splats()
-            with S2D.Trainer(W, H, n, device=device, count_pairs=True) as tc:
+            with S2D.Trainer(W, H, n, device=device, count_pairs=True, fp16_images=args.fp16_images) as tc:
                 tc.set_target_synthetic()
                 tc.set_splats(sp)
                 tc.forward()
