@@ -223,7 +223,7 @@ int s2d_bind_grads_device(s2d_ctx* ctx, void* grads_device);
 /* Device address of the gradient buffer currently in use. */
 void* s2d_grads_device_ptr(s2d_ctx* ctx);
 /* The hipStream_t the context queues its work on (s2d_config.stream, or the one it created): a caller that puts its
- * own device work between two calls -- the RCCL all-reduce of host/splat2d_train.cpp --gpus N -- queues it here. */
+ * own device work between two calls -- the RCCL all-reduce and the peer copies of s2d_multi -- queues it here. */
 void* s2d_stream(s2d_ctx* ctx);
 /* Per-iteration sums of squared errors of this slab kept on the device (ring of `capacity` doubles indexed by
  * iteration % capacity); lets a multi-GPU host reduce them once after many steps instead of every iteration. */
