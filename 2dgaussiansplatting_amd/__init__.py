@@ -72,7 +72,7 @@ ABI_SYMBOLS = [
     "s2d_halo_masks", "s2d_halo_commit", "s2d_rows_gather", "s2d_rows_scatter", "s2d_grads_combine",
     "s2d_multi_create", "s2d_multi_destroy", "s2d_multi_last_error", "s2d_multi_device_count", "s2d_multi_set_target",
     "s2d_multi_set_target_synthetic", "s2d_multi_init_splats", "s2d_multi_set_splats", "s2d_multi_get_splats",
-    "s2d_multi_set_adam", "s2d_multi_get_adam", "s2d_multi_step", "s2d_multi_get_image", "s2d_multi_exchange_info",
+    "s2d_multi_set_adam", "s2d_multi_get_adam", "s2d_multi_step", "s2d_multi_get_image", "s2d_multi_exchange_info", "s2d_multi_forward",
 ]
 
 _lib = None
@@ -153,6 +153,7 @@ def load_library(path=None):
     sig("s2d_multi_step", [vp, i32, u32, vp])
     sig("s2d_multi_get_image", [vp, vp])
     sig("s2d_multi_exchange_info", [vp, vp])
+    sig("s2d_multi_forward", [vp])
     if path == _build.LIB_PATH:
         _lib = L
     return L
@@ -446,6 +447,9 @@ class MultiTrainer:
         flags = S2D_STEP_OPTIMIZE_OPACITY if self.optimize_opacity else 0
         self._ck(self.L.s2d_multi_step(self._h, int(iters), flags, _p(out) if want_mse else None))
         return out
+
+    def forward(self):
+        self._ck(self.L.s2d_multi_forward(self._h))
 
     def get_image(self):
         a = np.zeros((self.H, self.W, 4), dtype=np.float32)

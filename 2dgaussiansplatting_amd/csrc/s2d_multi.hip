@@ -108,7 +108,7 @@ struct Barrier {
     }
 };
 
-enum Command { CMD_NONE = 0, CMD_STEP, CMD_HOLD, CMD_QUIT };
+enum Command { CMD_NONE = 0, CMD_STEP, CMD_HOLD, CMD_FORWARD, CMD_QUIT };
 enum Scheme { SCHEME_NONE = 0, SCHEME_OWNERSHIP = 1, SCHEME_REPLICATED = 2 };
 constexpr int kStopped = -1; // a rank that stopped because another one failed (never reported to the caller)
 
@@ -588,6 +588,10 @@ void worker_main(s2d_multi* m, int rank)
             rc = hold_fresh(m, rank);
             if (rc != S2D_OK) m->barrier.abort();
         }
+        if (cmd == CMD_FORWARD) { // the rank's rows of image0 from the current parameters (it holds every splat that reaches them)
+            rc = s2d_forward(m->ctx[(size_t)rank]);
+            if (rc == S2D_OK) rc = s2d_synchronize(m->ctx[(size_t)rank]);
+        }
         {
             std::lock_guard<std::mutex> lk(m->m);
             m->rank_rc[(size_t)rank] = rc;
@@ -883,6 +887,13 @@ int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out)
         }
     }
     return S2D_OK;
+}
+
+int s2d_multi_forward(s2d_multi* m)
+{
+    if (!m) return S2D_E_INVALID;
+    run_command(m, CMD_FORWARD);
+    return first_failure(m, "s2d_multi_forward");
 }
 
 int s2d_multi_get_image(s2d_multi* m, float* rgba32f)

@@ -12,9 +12,10 @@
 //   splat2d_train --synthetic 4096x4096 --splats 1000000 --iters 100 --quiet
 //   splat2d_train --synthetic 4096x4096 --splats 1000000 --iters 100 --quiet --gpus 8
 //
-// --gpus N (north_star's scheme): the same loop on a multi-device handle (s2d_multi_*): the image
-// cut into N row slabs, splats and Adam state replicated, the N x 9 fp32 gradient arrays all-reduced in place with
-// RCCL over xGMI between the backward pass and the Adam step -- all inside the library.
+// --gpus N: the same loop, with every option, on a multi-device handle (s2d_multi_*): the image cut
+// into N row slabs, one context per GPU, and between the backward pass and the Adam step either the holders of a
+// boundary splat swap its gradient rows by peer-to-peer copies (slab ownership, default) or RCCL all-reduces all
+// N x 9 gradients over xGMI (--exchange dense, north_star's scheme) -- all inside the library.
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -73,71 +74,85 @@ int usage()
     return 2;
 }
 
+// One context, or a multi-device handle, behind the same calls: what main() below talks to.
+struct Session {
+    s2d_ctx* ctx = nullptr;
+    s2d_multi* multi = nullptr;
+    bool is_multi = false;
+
+    const char* last_error() const { return is_multi ? s2d_multi_last_error(multi) : s2d_last_error(ctx); }
+    int create(const Options& o, int W, int H)
+    {
+        s2d_config cfg;
+        std::memset(&cfg, 0, sizeof(cfg));
+        cfg.struct_size = sizeof(cfg);
+        cfg.width = W;
+        cfg.height = H;
+        cfg.n_splats = o.n_splats; // int NSplat = 1024; main.cpp:271
+        cfg.rebin_interval = o.rebin_interval;
+        is_multi = o.gpus > 1 || std::getenv("S2D_TRAIN_FORCE_MULTI"); // (the variable sends --gpus 1 through the handle)
+        if (!is_multi) {
+            cfg.device = o.device;
+            return s2d_create(&cfg, &ctx);
+        }
+        std::vector<int32_t> devs((size_t)o.gpus);
+        for (int r = 0; r < o.gpus; r++) devs[(size_t)r] = o.device + (o.share_gpu ? 0 : r);
+        return s2d_multi_create(&cfg, devs.data(), o.gpus,
+                                (o.share_gpu ? S2D_MULTI_SHARE_GPU : 0u) | (o.replicated ? S2D_MULTI_REPLICATED : 0u), &multi);
+    }
+    void destroy()
+    {
+        if (ctx) s2d_destroy(ctx);
+        if (multi) s2d_multi_destroy(multi);
+        ctx = nullptr;
+        multi = nullptr;
+    }
+    int set_target(const std::vector<float>& rgba)
+    {
+        if (rgba.empty()) return is_multi ? s2d_multi_set_target_synthetic(multi) : s2d_set_target_synthetic(ctx);
+        return is_multi ? s2d_multi_set_target(multi, rgba.data()) : s2d_set_target(ctx, rgba.data());
+    }
+    int init() { return is_multi ? s2d_multi_init_splats(multi) : s2d_init_splats(ctx); }
+    int set_splats(const s2d_splat* p) { return is_multi ? s2d_multi_set_splats(multi, p) : s2d_set_splats(ctx, p); }
+    int get_splats(s2d_splat* p) { return is_multi ? s2d_multi_get_splats(multi, p) : s2d_get_splats(ctx, p); }
+    int set_adam(const s2d_splat_adam* p, float b1, float b2, int32_t it)
+    {
+        return is_multi ? s2d_multi_set_adam(multi, p, b1, b2, it) : s2d_set_adam(ctx, p, b1, b2, it);
+    }
+    int get_adam(s2d_splat_adam* p, float* b1, float* b2, int32_t* it)
+    {
+        return is_multi ? s2d_multi_get_adam(multi, p, b1, b2, it) : s2d_get_adam(ctx, p, b1, b2, it);
+    }
+    int step(int iters, uint32_t flags, double* mse) { return is_multi ? s2d_multi_step(multi, iters, flags, mse) : s2d_step(ctx, iters, flags, mse); }
+    int forward() { return is_multi ? s2d_multi_forward(multi) : s2d_forward(ctx); }
+    int get_image(float* rgba) { return is_multi ? s2d_multi_get_image(multi, rgba) : s2d_get_image(ctx, rgba); }
+    // how the devices were kept consistent, for the summary line
+    std::string exchange_summary(const Options& o)
+    {
+        int64_t info[4] = {0, 0, 0, 0};
+        if (!is_multi || s2d_multi_exchange_info(multi, info) != S2D_OK) return "";
+        char how[240];
+        if (info[0] == 2)
+            std::snprintf(how, sizeof(how), ", %d ranks: row slabs; replicated state, %s of all gradients", o.gpus,
+                          o.share_gpu ? "host-staged sum (ranks share one GPU)" : "RCCL all-reduce");
+        else if (info[0] == 1)
+            std::snprintf(how, sizeof(how), ", %d ranks: row slabs; slab ownership, %lld gradient rows swapped per iteration by %s, %lld state rows handed over",
+                          o.gpus, (long long)info[1], o.share_gpu ? "device copies (ranks share one GPU)" : "peer-to-peer copies", (long long)info[2]);
+        else
+            std::snprintf(how, sizeof(how), ", %d ranks: one device, nothing to exchange", o.gpus);
+        return how;
+    }
+};
+
 #define CK(call)                                                                        \
     do {                                                                                \
         int rc_ = (call);                                                               \
         if (rc_ != S2D_OK) {                                                            \
-            std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, s2d_last_error(ctx));    \
-            if (ctx) s2d_destroy(ctx);                                                  \
+            std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, S.last_error());         \
+            S.destroy();                                                                \
             return rc_ == S2D_E_NONFINITE ? 3 : 1; /* the reference abort()s, main.cpp:752-785 */ \
         }                                                                               \
     } while (0)
-
-// ---- --gpus N: the same frame loop on a multi-device handle (s2d_multi_*, csrc/s2d_multi.hip) ----------------------
-int run_multi(const Options& o, int W, int H, const std::vector<float>& imageRef)
-{
-    std::vector<int32_t> devs((size_t)o.gpus);
-    for (int r = 0; r < o.gpus; r++) devs[(size_t)r] = o.device + (o.share_gpu ? 0 : r);
-    s2d_config cfg;
-    std::memset(&cfg, 0, sizeof(cfg));
-    cfg.struct_size = sizeof(cfg);
-    cfg.width = W;
-    cfg.height = H;
-    cfg.n_splats = o.n_splats;
-    cfg.rebin_interval = o.rebin_interval;
-    s2d_multi* m = nullptr;
-#define CKM(call)                                                                         \
-    do {                                                                                  \
-        int rc_ = (call);                                                                 \
-        if (rc_ != S2D_OK) {                                                              \
-            std::fprintf(stderr, "%s -> %d: %s\n", #call, rc_, s2d_multi_last_error(m));  \
-            if (m) s2d_multi_destroy(m);                                                  \
-            return rc_ == S2D_E_NONFINITE ? 3 : 1; /* the reference abort()s */           \
-        }                                                                                 \
-    } while (0)
-    CKM(s2d_multi_create(&cfg, devs.data(), o.gpus,
-                         (o.share_gpu ? S2D_MULTI_SHARE_GPU : 0u) | (o.replicated ? S2D_MULTI_REPLICATED : 0u), &m));
-    if (imageRef.empty()) CKM(s2d_multi_set_target_synthetic(m));
-    else CKM(s2d_multi_set_target(m, imageRef.data()));
-    CKM(s2d_multi_init_splats(m)); // init(); main.cpp:307
-    std::vector<double> mse((size_t)o.batch);
-    const auto t0 = std::chrono::steady_clock::now();
-    int iterations = 0;
-    while (iterations < o.iters) { // while (pr::NextFrame() == false), main.cpp:334
-        int k = o.batch;
-        if (k > o.iters - iterations) k = o.iters - iterations;
-        CKM(s2d_multi_step(m, k, o.optimize_opacity ? S2D_STEP_OPTIMIZE_OPACITY : 0u, mse.data()));
-        if (!o.quiet)
-            for (int j = 0; j < k; j++) std::printf("%d itr, mse %.4f\n", iterations + j, mse[(size_t)j]); // main.cpp:807
-        iterations += k;
-    }
-    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    int64_t info[4] = {0, 0, 0, 0};
-    CKM(s2d_multi_exchange_info(m, info));
-    char how[200];
-    if (info[0] == 2)
-        std::snprintf(how, sizeof(how), "replicated state, %s of all gradients", o.share_gpu ? "host-staged sum (ranks share one GPU)" : "RCCL all-reduce");
-    else if (info[0] == 1)
-        std::snprintf(how, sizeof(how), "slab ownership, %lld gradient rows swapped per iteration by %s, %lld state rows handed over",
-                      (long long)info[1], o.share_gpu ? "device copies (ranks share one GPU)" : "peer-to-peer copies", (long long)info[2]);
-    else
-        std::snprintf(how, sizeof(how), "one device, nothing to exchange");
-    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats, %d ranks: row slabs; %s)\n", o.iters, secs,
-                 secs > 0 ? o.iters / secs : 0.0, W, H, o.n_splats, o.gpus, how);
-#undef CKM
-    s2d_multi_destroy(m);
-    return 0;
-}
 
 } // namespace
 
@@ -205,28 +220,10 @@ int main(int argc, char** argv)
     }
 
     if (o.gpus < 1) return usage();
-    if (o.gpus > 1 || std::getenv("S2D_TRAIN_FORCE_MULTI")) { // (the variable sends --gpus 1 through the multi-device handle)
-        if (!o.load_ckpt.empty() || !o.save_ckpt.empty() || !o.out_image.empty() || !o.overlay.empty() || o.restart_at >= 0 ||
-            o.opacity_from > 0) {
-            std::fprintf(stderr, "--gpus: checkpoints, image output, --restart-at and --opacity-from are single-GPU options\n");
-            return 2;
-        }
-        return run_multi(o, W, H, imageRef);
-    }
-
-    s2d_ctx* ctx = nullptr;
-    s2d_config cfg;
-    std::memset(&cfg, 0, sizeof(cfg));
-    cfg.struct_size = sizeof(cfg);
-    cfg.width = W;
-    cfg.height = H;
-    cfg.n_splats = o.n_splats; // int NSplat = 1024; main.cpp:271
-    cfg.device = o.device;
-    cfg.rebin_interval = o.rebin_interval;
-    CK(s2d_create(&cfg, &ctx));
-    if (!o.image.empty()) CK(s2d_set_target(ctx, imageRef.data()));
-    else CK(s2d_set_target_synthetic(ctx));
-    CK(s2d_init_splats(ctx)); // init(); main.cpp:307
+    Session S;
+    CK(S.create(o, W, H));
+    CK(S.set_target(imageRef)); // (empty: the synthetic target is generated on the device)
+    CK(S.init());               // init(); main.cpp:307
 
     int iterations = 0; // main.cpp:278
     if (!o.load_ckpt.empty()) {
@@ -241,11 +238,11 @@ int main(int argc, char** argv)
         if (f) std::fclose(f);
         if (!ok) {
             std::fprintf(stderr, "cannot load checkpoint %s (wrong size or format)\n", o.load_ckpt.c_str());
-            s2d_destroy(ctx);
+            S.destroy();
             return 1;
         }
-        CK(s2d_set_splats(ctx, sp.data()));
-        CK(s2d_set_adam(ctx, ad.data(), h.beta1t, h.beta2t, h.iterations));
+        CK(S.set_splats(sp.data()));
+        CK(S.set_adam(ad.data(), h.beta1t, h.beta2t, h.iterations));
         iterations = h.iterations;
         o.iters += iterations; // --iters counts iterations to run from the checkpoint
     }
@@ -254,7 +251,7 @@ int main(int argc, char** argv)
     const auto t0 = std::chrono::steady_clock::now();
     while (iterations < o.iters) { // while (pr::NextFrame() == false), main.cpp:334
         if (iterations == o.restart_at) { // ImGui::Button("Restart"), main.cpp:828-831: init() also sets
-            CK(s2d_init_splats(ctx));     // iterations = 0 (main.cpp:281), so the trace restarts at "0 itr"
+            CK(S.init());                 // iterations = 0 (main.cpp:281), so the trace restarts at "0 itr"
             o.iters -= iterations;        // --iters is the number of frames to run in total
             iterations = 0;
             o.restart_at = -1;
@@ -264,15 +261,15 @@ int main(int argc, char** argv)
         if (o.optimize_opacity && iterations < o.opacity_from && iterations + k > o.opacity_from) k = o.opacity_from - iterations;
         if (o.restart_at > iterations && iterations + k > o.restart_at) k = o.restart_at - iterations;
         const bool opacity_now = o.optimize_opacity && iterations >= o.opacity_from; // bool optimizeOpacity, main.cpp:317
-        CK(s2d_step(ctx, k, opacity_now ? S2D_STEP_OPTIMIZE_OPACITY : 0u, mse.data()));
+        CK(S.step(k, opacity_now ? S2D_STEP_OPTIMIZE_OPACITY : 0u, mse.data()));
         if (!o.quiet)
             for (int j = 0; j < k; j++) std::printf("%d itr, mse %.4f\n", iterations + j, mse[(size_t)j]); // main.cpp:807
         iterations += k; // main.cpp:809
         frames += k;
     }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats)\n", frames, secs,
-                 secs > 0 ? frames / secs : 0.0, W, H, o.n_splats);
+    std::fprintf(stderr, "%d iterations in %.3f s = %.2f it/s (%dx%d, %d splats%s)\n", frames, secs,
+                 secs > 0 ? frames / secs : 0.0, W, H, o.n_splats, S.exchange_summary(o).c_str());
     int exit_code = 0; // an output file that cannot be written is an error, reported after everything else was tried
 
     if (!o.save_ckpt.empty()) {
@@ -281,8 +278,8 @@ int main(int argc, char** argv)
         h.n_splats = (uint32_t)o.n_splats; h.width = (uint32_t)W; h.height = (uint32_t)H;
         std::vector<s2d_splat> sp((size_t)o.n_splats);
         std::vector<s2d_splat_adam> ad((size_t)o.n_splats);
-        CK(s2d_get_splats(ctx, sp.data()));
-        CK(s2d_get_adam(ctx, ad.data(), &h.beta1t, &h.beta2t, &h.iterations));
+        CK(S.get_splats(sp.data()));
+        CK(S.get_adam(ad.data(), &h.beta1t, &h.beta2t, &h.iterations));
         FILE* f = std::fopen(o.save_ckpt.c_str(), "wb");
         const bool ok = f && std::fwrite(&h, sizeof(h), 1, f) == 1 &&
                         std::fwrite(sp.data(), sizeof(s2d_splat), sp.size(), f) == sp.size() &&
@@ -295,8 +292,8 @@ int main(int argc, char** argv)
     }
     if (!o.out_image.empty() || !o.overlay.empty()) {
         std::vector<float> image0((size_t)W * H * 4);
-        CK(s2d_forward(ctx));
-        CK(s2d_get_image(ctx, image0.data())); // tex0->upload(image0), main.cpp:794
+        CK(S.forward());
+        CK(S.get_image(image0.data())); // tex0->upload(image0), main.cpp:794
         const s2dio::Image8 im = s2dio::quantise(image0, W, H);
         if (!o.out_image.empty() && !s2dio::save_image(o.out_image, im)) {
             std::fprintf(stderr, "cannot write %s\n", o.out_image.c_str());
@@ -304,7 +301,7 @@ int main(int argc, char** argv)
         }
         if (!o.overlay.empty()) { // the reference's splat visualisation, main.cpp:441-485
             std::vector<s2d_splat> sp((size_t)o.n_splats);
-            CK(s2d_get_splats(ctx, sp.data()));
+            CK(S.get_splats(sp.data()));
             s2dio::Image8 big = s2dio::upscale(im, o.overlay_scale);
             s2dio::draw_splat_overlay(&big, sp, o.overlay_scale, o.overlay_stride);
             if (!s2dio::save_image(o.overlay, big)) {
@@ -313,6 +310,6 @@ int main(int argc, char** argv)
             }
         }
     }
-    s2d_destroy(ctx);
+    S.destroy();
     return exit_code;
 }

@@ -264,7 +264,9 @@ int s2d_multi_get_adam(s2d_multi* m, s2d_splat_adam* adams, float* beta1t, float
 /* `iters` whole iterations (main.cpp:414-809) on all devices; mse_out as for s2d_step (the slabs' squared errors are
  * added in slab order).  S2D_E_NONFINITE where the reference would abort(). */
 int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out);
-/* image0 of the last iteration of the last s2d_multi_step, assembled from the slabs. */
+/* Forward rasteriser (main.cpp:414-546) of the current parameters on every device's rows, e.g. for display (main.cpp:794). */
+int s2d_multi_forward(s2d_multi* m);
+/* image0 of the last s2d_multi_forward, or of the last iteration of the last s2d_multi_step, assembled from the slabs. */
 int s2d_multi_get_image(s2d_multi* m, float* rgba32f);
 /* out4: scheme in use (0 none: one device, 1 slab ownership, 2 replicated), gradient rows swapped per iteration (all
  * ranks), state rows handed over so far, splats held summed over the ranks (n_splats * n_devices when replicated). */

@@ -1197,3 +1197,34 @@ def test_multi_device_handle_reports_nonfinite_like_the_single_context(replicate
         assert ei.value.code == 3
         m.init()                      # usable again after a restart
         assert np.isfinite(m.step(2)).all()
+
+
+@pytest.mark.parametrize("exchange", ["halo", "dense"])
+def test_cpp_host_run_control_works_on_the_multi_device_handle(tmp_path, exchange):
+    """splat2d_train --gpus 3 --share-gpu with the options the single-GPU loop has: a checkpoint
+    written by a 3-rank run (state gathered from the holders) continues under a 2-rank run and under one context
+    along the trajectory of an uninterrupted single-context run; Restart starts the trace over; --out-image of the
+    multi-device run is the single context's frame to within the fp32 summation order of the gradients."""
+    import subprocess
+    exe = S2D._build.build_host_program()
+    multi = ["--share-gpu", "--exchange", exchange]
+    ck = str(tmp_path / "ck.bin")
+    base = [exe, "--image", MINI, "--splats", "1024"]
+    a = subprocess.run(base + ["--iters", "70", "--batch", "35", "--save-checkpoint", ck, "--gpus", "3"] + multi,
+                       capture_output=True, text=True, check=True).stdout.strip().splitlines()   # (a hold-set refresh at 64)
+    b = subprocess.run(base + ["--iters", "6", "--load-checkpoint", ck, "--gpus", "2", "--out-image", str(tmp_path / "m.ppm")] + multi,
+                       capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    c = subprocess.run(base + ["--iters", "6", "--load-checkpoint", ck, "--out-image", str(tmp_path / "s.ppm")],
+                       capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    full = subprocess.run(base + ["--iters", "76", "--batch", "38"], capture_output=True, text=True, check=True).stdout.strip().splitlines()
+    val = lambda lines: [float(l.split("mse")[1]) for l in lines]
+    assert a[0] == "0 itr, mse 5934.9042" and [int(l.split()[0]) for l in b] == list(range(70, 76)) == [int(l.split()[0]) for l in c]
+    np.testing.assert_allclose(val(a + b), val(full), rtol=2e-4)    # 76 iterations apart in summation order
+    np.testing.assert_allclose(val(b), val(c), rtol=2e-5)           # the same checkpoint, 6 iterations
+    im_m = np.frombuffer(open(tmp_path / "m.ppm", "rb").read()[15:], dtype=np.uint8).astype(int)
+    im_s = np.frombuffer(open(tmp_path / "s.ppm", "rb").read()[15:], dtype=np.uint8).astype(int)
+    assert im_m.size == 268 * 213 * 3 and np.abs(im_m - im_s).max() <= 1 and (im_m != im_s).mean() < 0.01
+    r = subprocess.run(base + ["--iters", "5", "--restart-at", "3", "--gpus", "2"] + multi, capture_output=True, text=True,
+                       check=True).stdout.strip().splitlines()
+    assert [int(l.split()[0]) for l in r] == [0, 1, 2, 0, 1] and r[3] == "0 itr, mse 5934.9042"
+    np.testing.assert_allclose(val(r[3:]), val(r[:2]), rtol=2e-5)
