@@ -289,9 +289,13 @@ def test_bench_one_rank_through_rccl_as_the_driver_launches_it():
     assert p.returncode == 0, p.stderr[-3000:]
     plain = json.loads(p.stdout.strip().splitlines()[-1])
     assert plain["exchange_rank0"]["scheme"] == "none"
-    for k, exchange in enumerate(("dense", "halo")):
+    import socket
+    for exchange in ("dense", "halo"):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
         p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-                            "127.0.0.1", "--master-port", str(29611 + k), os.path.join(root, "bench.py"), "--gpus", "1",
+                            "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1",
                             "--exchange", exchange] + common, env=dict(env, S2D_BENCH_FORCE_DIST="1"), capture_output=True,
                            text=True, timeout=900)
         assert p.returncode == 0, p.stderr[-3000:]
