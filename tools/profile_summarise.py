@@ -3,7 +3,8 @@
 
   kernel stats : profile_summarise.py stats  <dir> <out.csv>      (copies the *_kernel_stats.csv of --kernel-trace --stats)
   counters     : profile_summarise.py pmc    <dir> [<dir> ...] <out.csv>
-                 per kernel name: launches and the per-launch mean of every counter found in *_counter_collection.csv
+                 per kernel name: launches, working launches and the per-WORKING-launch mean of every counter found in
+                 *_counter_collection.csv (void optimistic launches -- counter < 5 % of the kernel's median -- left out)
   working      : profile_summarise.py working <dir> <out.csv>
                  per kernel, from the kernel TRACE: all launches, and the launches that did work -- the first raster kernel of
                  an iteration is launched optimistically and returns at once (~22 us) when the tile lists turn out stale
@@ -35,23 +36,40 @@ def main():
             g.write(f.read())
         print("wrote", sys.argv[3])
     elif mode == "pmc":
+        import statistics
         dirs, out = sys.argv[2:-1], sys.argv[-1]
-        acc = defaultdict(lambda: defaultdict(float))   # kernel -> counter -> sum
-        cnt = defaultdict(lambda: defaultdict(set))     # kernel -> counter -> dispatch ids
+        # A launch is 'void' when some counter of its pass reads under 5 % of the kernel's median for that counter: the first
+        # raster kernel of an iteration is launched optimistically and returns at once when the tile lists turn out stale
+        # (one per list rebuild).  Dispatch ids belong to one pass (one process), so launches are sorted pass by pass.
+        # Means are over the launches that WORK; the all-launch count is kept beside them.
+        mean, nall, nwork = defaultdict(dict), defaultdict(int), defaultdict(int)
         for d in dirs:
+            val = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))  # kernel -> counter -> dispatch -> value
             with open(find(d, "counter_collection.csv")) as f:
-                for row in csv.DictReader(f):
-                    k = short(row["Kernel_Name"])
-                    c = row["Counter_Name"]
-                    acc[k][c] += float(row["Counter_Value"])
-                    cnt[k][c].add(row["Dispatch_Id"])
-        counters = sorted({c for k in acc for c in acc[k]})
+                for row in csv.DictReader(f):  # a counter's rows of one dispatch (e.g. one per XCD) are added up
+                    val[short(row["Kernel_Name"])][row["Counter_Name"]][row["Dispatch_Id"]] += float(row["Counter_Value"])
+            for k in val:
+                ids = set().union(*[set(val[k][c]) for c in val[k]])
+                void = set()
+                for c in val[k]:
+                    med = statistics.median(val[k][c].values())
+                    if med > 0:
+                        void |= {i for i, x in val[k][c].items() if x < 0.05 * med}
+                work = ids - void
+                for c in val[k]:
+                    v = [val[k][c][i] for i in work if i in val[k][c]]
+                    mean[k][c] = sum(v) / max(len(v), 1)
+                nall[k] = max(nall[k], len(ids))
+                nwork[k] = max(nwork[k], len(work))
+        counters = sorted({c for k in mean for c in mean[k]})
+        val = mean
         with open(out, "w") as g:
-            g.write("# per-launch means; rocprofv3 --pmc, one pass per directory: %s\n" % " ".join(os.path.basename(os.path.normpath(d)) for d in dirs))
-            g.write("kernel,launches," + ",".join(counters) + "\n")
-            for k in sorted(acc, key=lambda k: -sum(acc[k].values())):
-                n = max(len(cnt[k][c]) for c in cnt[k])
-                g.write("%s,%d,%s\n" % (k.replace(",", ";"), n, ",".join("%.6g" % (acc[k][c] / max(len(cnt[k][c]), 1)) if c in acc[k] else "" for c in counters)))
+            g.write("# per-launch means over the launches that did work (a launch whose counter reads < 5 %% of the kernel's median "
+                    "is void and left out); rocprofv3 --pmc, one pass per directory: %s\n" % " ".join(os.path.basename(os.path.normpath(d)) for d in dirs))
+            g.write("kernel,launches,working_launches," + ",".join(counters) + "\n")
+            for k in sorted(val, key=lambda k: -sum(mean[k].values()) * nwork[k]):
+                g.write("%s,%d,%d,%s\n" % (k.replace(",", ";"), nall[k], nwork[k],
+                                           ",".join("%.6g" % mean[k][c] if c in mean[k] else "" for c in counters)))
         print("wrote", out)
     elif mode == "working":
         import statistics
@@ -84,7 +102,8 @@ def main():
         out = {
             "source": "%s (rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes; tools/gpu_profile_round.sh)" % os.path.basename(sys.argv[2]),
             "workload": "4096x4096 synthetic, 1,000,000 Gaussians, 1 GPU (python3 bench.py)",
-            "kernel": r[0], "launches": int(r[1]),
+            "kernel": r[0], "launches": int(r[1]), "working_launches": int(r[hdr.index("working_launches")]),
+            "note": "per-launch means over the launches that did work (void optimistic launches left out)",
             "FETCH_SIZE_KB_per_launch": fetch_kb, "WRITE_SIZE_KB_per_launch": write_kb,
             "correction": "gfx950: FETCH_SIZE tallies a 128-B request of a wide coalesced read as 64 B, WRITE_SIZE is exact for 16-B "
                           "streaming stores and float atomics: bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (MI355X_MICROARCH.md, HBM section); "
