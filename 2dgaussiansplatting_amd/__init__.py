@@ -16,7 +16,8 @@ import numpy as np
 
 from . import _build
 
-__all__ = ["Trainer", "MultiTrainer", "S2DError", "load_library", "SPLAT_DTYPE", "ADAM_DTYPE", "STATUS_NAMES"]
+__all__ = ["Trainer", "MultiTrainer", "S2DError", "load_library", "hip_runtimes_mapped", "SPLAT_DTYPE", "ADAM_DTYPE",
+           "STATUS_NAMES"]
 
 # == struct Splat (main.cpp:85-93), 36 bytes; == struct SplatAdam (main.cpp:158-166), 72 bytes
 SPLAT_DTYPE = np.dtype([("pos", "<f4", 2), ("sx", "<f4"), ("sy", "<f4"), ("rot", "<f4"),
@@ -52,7 +53,8 @@ ROWS_GRADS, ROWS_SPLATS, ROWS_ADAM = 0, 1, 2  # S2D_ROWS_* (row arrays of the sl
 
 
 class _Stats(C.Structure):
-    _fields_ = [("pairs_binned", C.c_uint64), ("pairs_capacity", C.c_uint64), ("rebins", C.c_uint64),
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32),
+                ("pairs_binned", C.c_uint64), ("pairs_capacity", C.c_uint64), ("rebins", C.c_uint64),
                 ("fwd_visited", C.c_uint64), ("fwd_active", C.c_uint64), ("bwd_visited", C.c_uint64),
                 ("bwd_active", C.c_uint64), ("fwd_staged", C.c_uint64), ("bwd_staged", C.c_uint64),
                 ("fwd_wave_execs", C.c_uint64), ("bwd_wave_execs", C.c_uint64), ("bwd_lane_hist", C.c_uint64 * 65),
@@ -60,11 +62,13 @@ class _Stats(C.Structure):
                 ("fwd_staged_hit", C.c_uint64), ("fwd_rows_hit", C.c_uint64), ("bwd_quadrant_execs", C.c_uint64)]
 
 
-# every symbol include/splat2d.h declares
+ABI_VERSION = 2  # S2D_ABI_VERSION of include/splat2d.h as this binding was written (checked against the library at load)
+
+# every symbol include/splat2d.h and include/splat2d_test.h declare
 ABI_SYMBOLS = [
     "s2d_abi_version", "s2d_create", "s2d_destroy", "s2d_set_target", "s2d_set_target_synthetic",
     "s2d_init_splats", "s2d_set_splats", "s2d_get_splats", "s2d_set_adam", "s2d_get_adam", "s2d_forward",
-    "s2d_get_image", "s2d_backward", "s2d_forward_backward", "s2d_get_grads", "s2d_adam_step", "s2d_step", "s2d_get_mse",
+    "s2d_get_image", "s2d_get_image_rows", "s2d_backward", "s2d_forward_backward", "s2d_get_grads", "s2d_adam_step", "s2d_step", "s2d_get_mse",
     "s2d_bind_grads_device", "s2d_grads_device_ptr", "s2d_stream", "s2d_get_sqerr_trace", "s2d_synchronize", "s2d_get_stats",
     "s2d_get_rebuild_count",
     "s2d_last_error", "s2d_test_sincos", "s2d_test_sort_pairs", "s2d_test_exclusive_scan",
@@ -78,6 +82,53 @@ ABI_SYMBOLS = [
 _lib = None
 
 
+def hip_runtimes_mapped():
+    """Paths of the HIP runtime images (libamdhip64) mapped into this process."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    except OSError:
+        return []
+
+
+def _bind_process_hip_runtime():
+    """One HIP runtime per process.
+
+    libsplat2d_hip.so needs `libamdhip64.so.7` (its DT_NEEDED entry, the runtime's SONAME).  PyTorch's ROCm wheel bundles
+    its own copy of that runtime as torch/lib/libamdhip64.so -- same SONAME -- and its libraries ask for it as
+    `libamdhip64.so`:
+      * torch first: the bundled copy is loaded; our DT_NEEDED matches it by SONAME, nothing else is mapped;
+      * this library first: the dynamic linker resolves `libamdhip64.so.7` to /opt/rocm/lib, and a later `import torch`
+        asks for `libamdhip64.so`, which matches neither the name nor the SONAME of the loaded image, finds the bundled
+        file and maps a SECOND runtime: two HSA clients in one process, streams and device pointers of one unknown to
+        the other ("torch finds no HIP GPUs").
+    So, when no runtime is mapped yet and a PyTorch with a bundled runtime is installed, map THAT file first (by path,
+    without importing torch): ours then binds to it by SONAME and a later `import torch` finds the same file.
+    S2D_HIP_RUNTIME=system keeps the dynamic linker's choice (a process that never imports torch);
+    S2D_HIP_RUNTIME=<path> maps that file.
+    """
+    if hip_runtimes_mapped():
+        return  # a runtime is already in the process: the DT_NEEDED entry binds to it by SONAME
+    choice = os.environ.get("S2D_HIP_RUNTIME", "auto")
+    if choice == "system":
+        return
+    path = None
+    if choice not in ("auto", "torch"):
+        path = choice
+    else:
+        import importlib.util
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is not None and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                path = cand
+    if path:
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def load_library(path=None):
     """dlopen the HIP library.  Raises if it has not been built: there is no fallback."""
     global _lib
@@ -87,7 +138,13 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the trainer has no CPU fallback)" % path)
+    _bind_process_hip_runtime()
     L = C.CDLL(path)
+    mapped = hip_runtimes_mapped()
+    if len(mapped) > 1:
+        raise RuntimeError("two HIP runtimes are mapped into this process (%s): device pointers and streams of one mean "
+                           "nothing to the other.  Import this package before anything else loads a differently named "
+                           "libamdhip64, or point S2D_HIP_RUNTIME at the runtime the process uses" % ", ".join(mapped))
     vp, i32, u32, i64 = C.c_void_p, C.c_int32, C.c_uint32, C.c_int64
     ab = path != _build.LIB_PATH  # an A/B build of an older ABI may lack newer entry points (tools/gpu_ab.py)
 
@@ -101,6 +158,9 @@ def load_library(path=None):
             f.restype = restype
 
     sig("s2d_abi_version", restype=C.c_int)
+    if not ab and L.s2d_abi_version() != ABI_VERSION:
+        raise RuntimeError("%s was built for ABI version %d, this binding for %d: rebuild it (python -c 'import "
+                           "__graft_entry__ as g; g.build()')" % (path, L.s2d_abi_version(), ABI_VERSION))
     sig("s2d_create", [C.POINTER(_Config), C.POINTER(vp)])
     sig("s2d_destroy", [vp])
     if hasattr(L, "s2d_destroy"):
@@ -114,6 +174,7 @@ def load_library(path=None):
     sig("s2d_get_adam", [vp, vp, vp, vp, vp])
     sig("s2d_forward", [vp])
     sig("s2d_get_image", [vp, vp])
+    sig("s2d_get_image_rows", [vp, vp])
     sig("s2d_backward", [vp, u32])
     sig("s2d_forward_backward", [vp, u32])
     sig("s2d_get_grads", [vp, vp])
@@ -179,6 +240,7 @@ class Trainer:
         cfg.struct_size = C.sizeof(_Config)
         cfg.width, cfg.height, cfg.n_splats, cfg.device = self.W, self.H, self.n, int(device)
         cfg.row_begin, cfg.row_end = int(row_begin), int(row_end)
+        self.row_begin, self.row_end = (0, self.H) if (int(row_begin), int(row_end)) == (0, 0) else (int(row_begin), int(row_end))
         cfg.training_rate = float(training_rate)
         cfg.flags = ((S2D_CFG_COUNT_PAIRS if count_pairs else 0) | (S2D_CFG_FP16_IMAGES if fp16_images else 0) |
                      (S2D_CFG_DETERMINISTIC if deterministic else 0) | (S2D_CFG_EXACT_EXP if exact_exp else 0) |
@@ -267,6 +329,12 @@ class Trainer:
         self._ck(self.L.s2d_get_image(self._h, _p(a)))
         return a
 
+    def get_image_rows(self):
+        """The slab's rows of image0 only (row_begin .. row_end)."""
+        a = np.zeros((self.row_end - self.row_begin, self.W, 4), dtype=np.float32)
+        self._ck(self.L.s2d_get_image_rows(self._h, _p(a)))
+        return a
+
     def backward(self, skip_opacity_grad=None):
         """Backward pass.  skip_opacity_grad=None: skip dSplats.opacity exactly when optimize_opacity is off and
         `lean_backward` was requested (bench / training loops); False: always compute it, as the reference does."""
@@ -338,8 +406,9 @@ class Trainer:
     # -- diagnostics
     def stats(self):
         s = _Stats()
+        s.struct_size = C.sizeof(_Stats)
         self._ck(self.L.s2d_get_stats(self._h, C.byref(s)))
-        out = {k: getattr(s, k) for k, _ in _Stats._fields_}
+        out = {k: getattr(s, k) for k, _ in _Stats._fields_ if k not in ("struct_size", "reserved")}
         out["bwd_lane_hist"] = list(s.bwd_lane_hist)
         return out
 

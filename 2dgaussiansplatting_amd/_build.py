@@ -59,7 +59,8 @@ def _stale(target, deps):
 
 def build_hip_library(force=False, verbose=False):
     srcs = [os.path.join(CSRC, s) for s in HIP_SOURCES]
-    deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "splat2d.h")]
+    deps = srcs + [os.path.join(CSRC, h) for h in HIP_HEADERS] + [os.path.join(ROOT, "include", "splat2d.h"),
+                                                                   os.path.join(ROOT, "include", "splat2d_test.h")]
     if force or _stale(LIB_PATH, deps):
         os.makedirs(LIB_DIR, exist_ok=True)
         cmd = [hipcc()] + HIPCC_FLAGS + ["-o", LIB_PATH] + srcs

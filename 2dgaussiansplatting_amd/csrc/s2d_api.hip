@@ -1,17 +1,21 @@
 // s2d_api.hip -- the C ABI of include/splat2d.h: context, device memory, iteration sequencing.
 //
-// One iteration (main.cpp:414-809) is queued on the context's stream as
-//   raster_forward -> raster_backward (+ per-tile squared error) -> sqerr_finalize
-//   -> adam (+ projection of the updated splats and containment check for the next iteration)
-// and, when the tile lists have to be (re)built:  project -> count scan -> emit -> radix sort -> tile offsets.
-// The host never makes the GPU wait: it reads the 4-byte containment flag after launching the forward kernel
+// One iteration (main.cpp:414-809) of s2d_step is TWO launches on the context's stream:
+//   raster_fused (forward walk + backward walk + per-tile squared error of every tile)
+//   -> adam (+ the sum of the tile errors, + projection of the updated splats and the containment check for the next
+//      iteration)
+// s2d_forward / s2d_backward / s2d_adam_step queue the passes one by one (raster_forward, raster_backward, sqerr_finalize).
+// When the tile lists have to be (re)built:  project -> count scan -> emit -> radix sort -> tile offsets.
+// The host never makes the GPU wait: it reads the 4-byte containment flag after launching the raster kernel
 // optimistically, and the 4-byte pair count only when lists are rebuilt.
 #include "../../include/splat2d.h"
+#include "../../include/splat2d_test.h"
 
 #include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
@@ -64,6 +68,8 @@ struct s2d_ctx {
     int since_rebin = 0;
     float margin = 0.0f;
     // images
+    // image0 / imageRef (main.cpp:310, :254): the rows [row_begin, row_end) of this context's slab only -- a context
+    // never touches another row, so a 1/8 slab of 8192^2 holds 2 x 134 MB instead of 2 x 1.07 GB
     void* d_image0 = nullptr;  // RGBA32F, or 4 x fp16 per pixel with S2D_CFG_FP16_IMAGES
     void* d_ref = nullptr;
     bool half_images = false;
@@ -88,7 +94,7 @@ struct s2d_ctx {
     float good_beta1t = 1.0f, good_beta2t = 1.0f; // the three above at the last point known to be finite
     int good_iterations = 0;
     bool have_target = false;
-    bool have_forward = false;
+    bool have_forward = false;  // image0 holds the framebuffer of the CURRENT parameters (s2d_backward reads it)
     bool have_backward = false;
     bool sqerr_deferred = false; // the squared-error reduction of the last backward pass rides on the next Adam launch
     int last_sqerr_slot = -1;
@@ -267,7 +273,7 @@ int queue_raster(s2d_ctx* c, const RasterJob& job)
         c->check_seq++; // the new lists cover the current parameters: a stamp that asked for them matches nothing now
         if (int rc = launch_raster(c, false, job)) return rc;
     }
-    c->have_forward = true;
+    c->have_forward = !job.fused || job.write_image; // a fused launch told not to store image0 leaves an older frame there
     c->have_backward = false;
     return S2D_OK;
 }
@@ -410,6 +416,8 @@ int judge_status(s2d_ctx* c)
 
 double mse_norm(const s2d_ctx* c) { return (double)((long long)c->g.H * c->g.W * 3); }
 
+size_t slab_pixels(const s2d_ctx* c) { return (size_t)c->g.W * (size_t)(c->g.row_end - c->g.row_begin); }
+
 } // namespace
 
 extern "C" {
@@ -458,7 +466,8 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
         c->own_stream = true;
     }
 
-    const size_t n = std::max<size_t>((size_t)c->n, 1), px = (size_t)g.W * g.H; // >= 1 so that n == 0 still has buffers
+    const size_t n = std::max<size_t>((size_t)c->n, 1);           // >= 1 so that n == 0 still has buffers
+    const size_t px = (size_t)g.W * (size_t)(g.row_end - g.row_begin); // pixels of the slab: all this context stores
     S2D_HIP(c, dev_alloc(&c->d_splats, n * 9));
     S2D_HIP(c, dev_alloc(&c->d_adams, n * 18));
     S2D_HIP(c, dev_alloc(&c->d_grads_own, n * 9));
@@ -531,17 +540,19 @@ int s2d_set_target(s2d_ctx* c, const float* rgba32f)
 {
     if (!c || !rgba32f) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
-    const size_t px = (size_t)c->g.W * c->g.H, bytes = px * sizeof(float4);
+    // the caller hands over the whole image (main.cpp:254-259); a slab context uploads and keeps its own rows only
+    const size_t px = slab_pixels(c), bytes = px * sizeof(float4);
+    const float* src = rgba32f + (size_t)c->g.row_begin * c->g.W * 4;
     if (c->half_images) { // floats cross the boundary; the device keeps them as fp16 (round to nearest even)
         float4* tmp = nullptr;
         S2D_HIP(c, hipMalloc((void**)&tmp, bytes));
-        hipError_t e = hipMemcpyAsync(tmp, rgba32f, bytes, hipMemcpyHostToDevice, c->stream);
+        hipError_t e = hipMemcpyAsync(tmp, src, bytes, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) e = launch_convert_f32_to_f16(tmp, c->d_ref, px, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         (void)hipFree(tmp);
         S2D_HIP(c, e);
     } else {
-        S2D_HIP(c, hipMemcpyAsync(c->d_ref, rgba32f, bytes, hipMemcpyHostToDevice, c->stream));
+        S2D_HIP(c, hipMemcpyAsync(c->d_ref, src, bytes, hipMemcpyHostToDevice, c->stream));
         S2D_HIP(c, hipStreamSynchronize(c->stream));
     }
     c->have_target = true;
@@ -553,7 +564,7 @@ int s2d_set_target_synthetic(s2d_ctx* c)
 {
     if (!c) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
-    S2D_HIP(c, launch_synthetic_target(c->d_ref, c->half_images, c->g.W, c->g.H, c->stream));
+    S2D_HIP(c, launch_synthetic_target(c->d_ref, c->half_images, c->g.W, c->g.H, c->g.row_begin, c->g.row_end, c->stream));
     c->have_target = true;
     c->have_forward = c->have_backward = false;
     return S2D_OK;
@@ -632,24 +643,34 @@ int s2d_forward(s2d_ctx* c)
     return queue_forward(c);
 }
 
-int s2d_get_image(s2d_ctx* c, float* rgba32f)
+int s2d_get_image_rows(s2d_ctx* c, float* rgba32f_rows)
 {
-    if (!c || !rgba32f) return S2D_E_INVALID;
+    if (!c || !rgba32f_rows) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
-    const size_t px = (size_t)c->g.W * c->g.H, bytes = px * sizeof(float4);
+    const size_t px = slab_pixels(c), bytes = px * sizeof(float4);
     if (c->half_images) {
         float4* tmp = nullptr;
         S2D_HIP(c, hipMalloc((void**)&tmp, bytes));
         hipError_t e = launch_convert_f16_to_f32(c->d_image0, tmp, px, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(rgba32f, tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(rgba32f_rows, tmp, bytes, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         (void)hipFree(tmp);
         S2D_HIP(c, e);
         return S2D_OK;
     }
-    S2D_HIP(c, hipMemcpyAsync(rgba32f, c->d_image0, bytes, hipMemcpyDeviceToHost, c->stream));
+    S2D_HIP(c, hipMemcpyAsync(rgba32f_rows, c->d_image0, bytes, hipMemcpyDeviceToHost, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
     return S2D_OK;
+}
+
+int s2d_get_image(s2d_ctx* c, float* rgba32f)
+{
+    if (!c || !rgba32f) return S2D_E_INVALID;
+    // a full-size image goes back (main.cpp:794 uploads all of image0): this context's rows, zeros elsewhere
+    const size_t row_floats = (size_t)c->g.W * 4;
+    std::memset(rgba32f, 0, (size_t)c->g.row_begin * row_floats * sizeof(float));
+    std::memset(rgba32f + (size_t)c->g.row_end * row_floats, 0, (size_t)(c->g.H - c->g.row_end) * row_floats * sizeof(float));
+    return s2d_get_image_rows(c, rgba32f + (size_t)c->g.row_begin * row_floats);
 }
 
 int s2d_forward_backward(s2d_ctx* c, uint32_t flags)
@@ -875,13 +896,21 @@ int s2d_synchronize(s2d_ctx* c)
 
 int s2d_get_stats(s2d_ctx* c, s2d_stats* out)
 {
-    if (!c || !out) return S2D_E_INVALID;
+    // the struct as its first version (ABI 2) ends with bwd_quadrant_execs: a caller must have at least that
+    if (!c || !out || out->struct_size < (uint32_t)(offsetof(s2d_stats, bwd_quadrant_execs) + sizeof(uint64_t))) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
     PairCounters pc;
     S2D_HIP(c, hipMemcpyAsync(&pc, c->d_counters, sizeof(pc), hipMemcpyDeviceToHost, c->stream));
     S2D_HIP(c, hipMemcpyAsync(c->h_status, c->d_status, sizeof(DeviceStatus), hipMemcpyDeviceToHost, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
+    // filled in a full-size copy, handed back at the caller's size: a caller built against an older, shorter struct is
+    // never written past its end
+    const uint32_t caller_size = std::min<uint32_t>(out->struct_size, (uint32_t)sizeof(s2d_stats));
+    s2d_stats full;
+    s2d_stats* const dst = out;
+    out = &full;
     std::memset(out, 0, sizeof(*out));
+    out->struct_size = caller_size;
     out->pairs_binned = c->pairs;
     out->pairs_capacity = c->pair_capacity;
     out->rebins = c->rebins;
@@ -895,6 +924,7 @@ int s2d_get_stats(s2d_ctx* c, s2d_stats* out)
     out->bwd_quadrant_execs = pc.bwd_quadrant_execs;
     out->iterations = c->iterations;
     out->first_nonfinite_iteration = c->h_status->nonfinite ? c->h_status->first_nonfinite_iter : -1;
+    std::memcpy(dst, &full, caller_size);
     return S2D_OK;
 }
 

@@ -287,7 +287,8 @@ hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t
                        Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
                        const TileRect* rects, int check_stamp, int* host_stamp, SqerrJob sq, hipStream_t stream);
-hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, hipStream_t stream);
+// image_ref: rows [row_begin, row_end) of the W x H target
+hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, int row_begin, int row_end, hipStream_t stream);
 // RGBA32F <-> 4 x fp16 (round to nearest even) for images that cross the boundary as floats
 hipError_t launch_convert_f32_to_f16(const float4* src, void* dst, size_t pixels, hipStream_t stream);
 hipError_t launch_convert_f16_to_f32(const void* src, float4* dst, size_t pixels, hipStream_t stream);

@@ -29,8 +29,10 @@
 #include <atomic>
 #include <condition_variable>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -43,6 +45,7 @@ struct Rccl {
     void* lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr; // frees a communicator whose collective can no longer complete
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
@@ -53,9 +56,17 @@ bool load_rccl(Rccl* r, std::string* why)
     static Rccl cached;
     std::lock_guard<std::mutex> lk(m);
     if (!cached.lib) {
-        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            cached.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        // One RCCL per process, on the process's one HIP runtime: first an image that is already
+        // mapped -- PyTorch's wheel bundles RCCL as torch/lib/librccl.so with SONAME librccl.so.1, and a process that has
+        // imported torch must not get the system's copy beside it -- and only then a load by name (the system's librccl.so.1
+        // needs libamdhip64.so.7, which binds to whichever runtime the process already has, by SONAME).
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+            cached.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
             if (cached.lib) break;
+        }
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (cached.lib) break;
+            cached.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         }
         if (!cached.lib) {
             *why = std::string("cannot load librccl: ") + dlerror();
@@ -63,6 +74,7 @@ bool load_rccl(Rccl* r, std::string* why)
         }
         cached.CommInitAll = (decltype(cached.CommInitAll))dlsym(cached.lib, "ncclCommInitAll");
         cached.CommDestroy = (decltype(cached.CommDestroy))dlsym(cached.lib, "ncclCommDestroy");
+        cached.CommAbort = (decltype(cached.CommAbort))dlsym(cached.lib, "ncclCommAbort");
         cached.AllReduce = (decltype(cached.AllReduce))dlsym(cached.lib, "ncclAllReduce");
         cached.GetErrorString = (decltype(cached.GetErrorString))dlsym(cached.lib, "ncclGetErrorString");
         if (!cached.CommInitAll || !cached.CommDestroy || !cached.AllReduce || !cached.GetErrorString) {
@@ -188,6 +200,12 @@ struct s2d_multi {
     bool hold_valid = false;        // hold sets exist (otherwise every context holds, and has, everything)
     int hold_age = 0;               // iterations since they were made
     std::atomic<int> late{0};
+    // sent_seq[r]: exchanges (since the hold sets were planned) whose gather and hipEventRecord rank r's thread has ISSUED.
+    // A receiver may call hipStreamWaitEvent on r's event of exchange k only once r has recorded it -- the one thing the
+    // rank threads tell each other per iteration, pairwise and without sleeping (no barrier: the streams order the rest)
+    std::unique_ptr<std::atomic<unsigned>[]> sent_seq;
+    std::atomic<bool> comms_aborted{false};
+    bool dead = false;              // a collective was aborted: the communicators are gone, the handle must be re-created
     // command hand-out
     std::vector<std::thread> workers;
     std::mutex m;
@@ -325,6 +343,7 @@ int plan(s2d_multi* m, int r)
     H.total = total;
     H.n_rows = (int)rows.size();
     H.seq = 0;
+    m->sent_seq[(size_t)r].store(0u, std::memory_order_release); // every rank thread is behind a barrier here, none is waiting on it
     MHIP(m, r, H.d_send_ids.reserve((size_t)total));
     MHIP(m, r, H.d_send[0].reserve((size_t)total * 9));
     MHIP(m, r, H.d_send[1].reserve((size_t)total * 9));
@@ -505,23 +524,44 @@ int refresh(s2d_multi* m, int r)
     return settle_plans(m, r);
 }
 
+// Has rank p's thread issued (gathered + recorded the event of) exchange number `seq`?  Spins without sleeping: the
+// threads queue an iteration in tens of microseconds and run at the same pace, so the wait is short; a failed rank ends it.
+bool wait_issued(s2d_multi* m, int p, unsigned seq)
+{
+    const std::atomic<unsigned>& a = m->sent_seq[(size_t)p];
+    for (unsigned spins = 0; a.load(std::memory_order_acquire) < seq; spins++) {
+        if (m->barrier.broken) return false;
+        if (spins > 64) std::this_thread::yield();
+    }
+    return true;
+}
+
 // The iteration's exchange: the partial gradient rows of splats this rank shares go to their other holders, theirs
-// come here, and every holder adds the partials in rank order.
+// come here, and every holder adds the partials in rank order.  Stream-ordered: the rank gathers its rows into one of
+// two send buffers and records an event; on its OWN stream it waits for each neighbour's event of the same exchange and
+// copies its segment out of the neighbour's buffer.  The rank threads do not meet: a receiver only makes sure, pairwise,
+// that the sender's thread has already recorded that event (sent_seq) -- all `iters` iterations of a call are queued
+// without a barrier, the refreshes stay the only rendezvous.  Buffer b of exchange k is gathered again at k + 2: by then
+// this rank's stream has waited for every neighbour's event k + 1, which that neighbour recorded behind its copy of k
+// (exchanges are symmetric: who receives from a rank also sends to it), and the neighbour's thread called
+// hipStreamWaitEvent for k before it recorded k + 1, so re-recording the event at k + 2 cannot overtake that call.
 int exchange_grads(s2d_multi* m, int r)
 {
     HaloRank& H = m->halo[(size_t)r];
     if (!H.any_exchange) return S2D_OK;
     s2d_ctx* c = m->ctx[(size_t)r];
     hipStream_t stream = (hipStream_t)s2d_stream(c);
-    const int b = (int)(H.seq++ & 1u);
+    const unsigned seq = ++H.seq;
+    const int b = (int)((seq - 1u) & 1u);
     if (H.total) {
         if (int rc = s2d_rows_gather(c, S2D_ROWS_GRADS, H.d_send_ids.p, H.total, H.d_send[b].p)) return rc;
         MHIP(m, r, hipEventRecord(H.ev_sent[b], stream));
     }
-    if (!meet(m)) return kStopped; // every sender's event is on record: the copies below can wait for them
+    m->sent_seq[(size_t)r].store(seq, std::memory_order_release);
     for (int p = 0; p < m->world; p++) {
         const int cnt = H.splits[(size_t)p];
         if (p == r || cnt == 0) continue;
+        if (!wait_issued(m, p, seq)) return kStopped;
         const HaloRank& P = m->halo[(size_t)p];
         MHIP(m, r, hipStreamWaitEvent(stream, P.ev_sent[b], 0));
         MHIP(m, r, rank_copy(m, H.d_recv.p + (size_t)H.offsets[(size_t)p] * 9, r, P.d_send[b].p + (size_t)P.offsets[(size_t)r] * 9, p,
@@ -530,6 +570,19 @@ int exchange_grads(s2d_multi* m, int r)
     if (H.n_rows)
         if (int rc = s2d_grads_combine(c, H.d_rows.p, H.n_rows, H.d_src.p, m->world, H.d_recv.p)) return rc;
     return S2D_OK;
+}
+
+// Replicated state over RCCL: a rank that fails before it has queued its share of a collective leaves the others
+// waiting inside theirs for good.  Abort every communicator (RCCL then ends the kernels that wait for the missing
+// rank), once; the handle is dead afterwards -- s2d_multi_destroy and a new s2d_multi_create bring it back.
+void abort_collectives(s2d_multi* m)
+{
+    if (m->scheme != SCHEME_REPLICATED || m->share_gpu || m->comms.empty()) return;
+    if (m->comms_aborted.exchange(true)) return;
+    for (ncclComm_t& c : m->comms) {
+        if (c && m->rccl.CommAbort) (void)m->rccl.CommAbort(c);
+        if (m->rccl.CommAbort) c = nullptr; // aborted communicators are freed: nothing left to destroy
+    }
 }
 
 // One rank's share of s2d_multi_step: `iters` frames of main.cpp:334 on its rows.
@@ -560,6 +613,9 @@ int rank_step(s2d_multi* m, int rank)
     }
     std::vector<double>& mine = m->sqerr[(size_t)rank];
     mine.assign((size_t)m->step_iters, 0.0);
+    // A rank that failed on the way (not the finite guard below, which every replica sees alike and which leaves every
+    // collective queued): the others may already sit in an all-reduce that will never get this rank's share
+    if (rc != S2D_OK && rc != kStopped) abort_collectives(m);
     if (rc == S2D_OK && m->step_iters > 0) rc = s2d_get_sqerr_trace(c, m->step_first_iter, m->step_iters, mine.data());
     if (rc == S2D_OK) rc = s2d_synchronize(c); // the finite guard, main.cpp:752-785
     if (rc != S2D_OK) m->barrier.abort();      // the other ranks stop at their next barrier instead of waiting
@@ -642,6 +698,20 @@ int ensure_hold(s2d_multi* m)
     return S2D_OK;
 }
 
+// The s2d_multi_* calls select devices (hipSetDevice is per thread) from the CALLER's thread: put its device back on the
+// way out, a caller that shares the thread with other HIP code (torch) does not expect it to have moved.
+struct DeviceGuard {
+    int prev = -1;
+    DeviceGuard() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int refuse_dead(s2d_multi* m)
+{
+    return mfail(m, S2D_E_STATE, "a collective of this handle was aborted after a rank failed: its communicators are gone; "
+                                 "s2d_multi_destroy it and create a new one");
+}
+
 inline bool lowest_holder(uint32_t mask, int r) { return mask != 0u && (mask & (0u - mask)) == (1u << r); }
 
 // Slab ownership: the complete parameter or Adam array, every row from its lowest-ranked holder.
@@ -667,6 +737,7 @@ int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_de
     if (!cfg || !out || !devices || n_devices < 1 || n_devices > 32 || cfg->struct_size != sizeof(s2d_config)) return S2D_E_INVALID;
     *out = nullptr;
     if (cfg->row_begin != 0 || cfg->row_end != 0 || cfg->stream != nullptr) return S2D_E_INVALID; // the handle cuts the slabs itself
+    DeviceGuard guard;
     s2d_multi* m = new (std::nothrow) s2d_multi();
     if (!m) return S2D_E_NOMEM;
     *out = m; // handed out even on failure so that s2d_multi_last_error works; the caller destroys it
@@ -688,6 +759,8 @@ int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_de
     m->sqerr.resize((size_t)m->world);
     m->halo.resize((size_t)m->world);
     m->barrier.n = m->world;
+    m->sent_seq.reset(new std::atomic<unsigned>[(size_t)m->world]);
+    for (int r = 0; r < m->world; r++) m->sent_seq[(size_t)r].store(0u);
     m->bounds.resize((size_t)m->world + 1);
     for (int r = 0; r < m->world; r++) {
         s2d_config c = *cfg;
@@ -746,6 +819,7 @@ int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_de
 void s2d_multi_destroy(s2d_multi* m)
 {
     if (!m) return;
+    DeviceGuard guard;
     if (!m->workers.empty()) {
         {
             std::lock_guard<std::mutex> lk(m->m);
@@ -798,6 +872,7 @@ int s2d_multi_exchange_info(s2d_multi* m, int64_t* out4)
 int s2d_multi_set_target(s2d_multi* m, const float* rgba32f)
 {
     if (!m || !rgba32f) return S2D_E_INVALID;
+    DeviceGuard guard;
     S2D_EACH(m, "s2d_set_target", s2d_set_target(c, rgba32f));
     return S2D_OK;
 }
@@ -805,6 +880,7 @@ int s2d_multi_set_target(s2d_multi* m, const float* rgba32f)
 int s2d_multi_set_target_synthetic(s2d_multi* m)
 {
     if (!m) return S2D_E_INVALID;
+    DeviceGuard guard;
     S2D_EACH(m, "s2d_set_target_synthetic", s2d_set_target_synthetic(c));
     return S2D_OK;
 }
@@ -812,6 +888,7 @@ int s2d_multi_set_target_synthetic(s2d_multi* m)
 int s2d_multi_init_splats(s2d_multi* m)
 {
     if (!m) return S2D_E_INVALID;
+    DeviceGuard guard;
     S2D_EACH(m, "s2d_init_splats", s2d_init_splats(c)); // every replica: the same deterministic init(), main.cpp:280-305
     m->iterations = 0;
     m->hold_valid = false; // every replica is complete again: new hold sets at the next step
@@ -821,6 +898,7 @@ int s2d_multi_init_splats(s2d_multi* m)
 int s2d_multi_get_adam(s2d_multi* m, s2d_splat_adam* adams, float* beta1t, float* beta2t, int32_t* iterations)
 {
     if (!m) return S2D_E_INVALID;
+    DeviceGuard guard;
     if (m->scheme == SCHEME_OWNERSHIP && m->hold_valid && adams) {
         if (int rc = assemble(m, adams, [](s2d_ctx* c, s2d_splat_adam* p) { return s2d_get_adam(c, p, nullptr, nullptr, nullptr); })) return rc;
         adams = nullptr;
@@ -832,6 +910,7 @@ int s2d_multi_get_adam(s2d_multi* m, s2d_splat_adam* adams, float* beta1t, float
 int s2d_multi_set_splats(s2d_multi* m, const s2d_splat* splats)
 {
     if (!m || (!splats && m->n)) return S2D_E_INVALID;
+    DeviceGuard guard;
     if (m->scheme == SCHEME_OWNERSHIP && m->hold_valid) {
         // the replicas are about to hold everything again: complete their Adam state first (a rank has current
         // moments only for the splats it holds)
@@ -849,6 +928,7 @@ int s2d_multi_set_splats(s2d_multi* m, const s2d_splat* splats)
 int s2d_multi_get_splats(s2d_multi* m, s2d_splat* splats)
 {
     if (!m || (!splats && m->n)) return S2D_E_INVALID;
+    DeviceGuard guard;
     if (m->scheme == SCHEME_OWNERSHIP && m->hold_valid)
         return assemble(m, splats, [](s2d_ctx* c, s2d_splat* p) { return s2d_get_splats(c, p); });
     if (int rc = s2d_get_splats(m->ctx[0], splats)) return mfail(m, rc, "s2d_get_splats: %s", s2d_last_error(m->ctx[0]));
@@ -858,6 +938,7 @@ int s2d_multi_get_splats(s2d_multi* m, s2d_splat* splats)
 int s2d_multi_set_adam(s2d_multi* m, const s2d_splat_adam* adams, float beta1t, float beta2t, int32_t iterations)
 {
     if (!m || (!adams && m->n) || iterations < 0) return S2D_E_INVALID;
+    DeviceGuard guard;
     S2D_EACH(m, "s2d_set_adam", s2d_set_adam(c, adams, beta1t, beta2t, iterations)); // complete on every rank; hold sets unaffected
     m->iterations = iterations;
     return S2D_OK;
@@ -866,14 +947,25 @@ int s2d_multi_set_adam(s2d_multi* m, const s2d_splat_adam* adams, float beta1t, 
 int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out)
 {
     if (!m || iters < 0 || iters > (1 << 16)) return S2D_E_INVALID;
+    if (m->dead) return refuse_dead(m);
+    DeviceGuard guard;
     if (int rc = ensure_hold(m)) return rc;
     m->step_iters = iters;
     m->step_flags = flags;
     m->step_first_iter = m->iterations;
     run_command(m, CMD_STEP);
     if (int rc = first_failure(m, "s2d_multi_step")) {
-        int32_t it = 0; // where the replicas stand now (a non-finite stop winds the counters back, s2d_api.hip)
-        if (s2d_get_adam(m->ctx[0], nullptr, nullptr, nullptr, &it) == S2D_OK) m->iterations = it;
+        // Where the run stands now: a non-finite stop winds the counters of the rank that holds the splat back to the
+        // failing iteration (s2d_api.hip judge_status); with slab ownership the other ranks did not see it and are ahead.
+        // The earliest count is the iteration at which the reference abort()ed; the state is for inspection only, and
+        // s2d_multi_set_adam (which sets every rank's counters alike) comes before any further step.
+        int32_t earliest = INT32_MAX;
+        for (s2d_ctx* c : m->ctx) {
+            int32_t it = 0;
+            if (s2d_get_adam(c, nullptr, nullptr, nullptr, &it) == S2D_OK) earliest = std::min(earliest, it);
+        }
+        if (earliest != INT32_MAX) m->iterations = earliest;
+        if (m->comms_aborted.load()) m->dead = true;
         return rc;
     }
     m->iterations += iters;
@@ -892,6 +984,12 @@ int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out)
 int s2d_multi_forward(s2d_multi* m)
 {
     if (!m) return S2D_E_INVALID;
+    if (m->dead) return refuse_dead(m);
+    DeviceGuard guard;
+    // slab ownership: after set_splats / init_splats the hold sets (and with them each context's list of the splats it
+    // projects and rasterises) are stale until they are made afresh -- a splat that now reaches a rank's rows but was not
+    // in its old set would be missing from that slab of the image
+    if (int rc = ensure_hold(m)) return rc;
     run_command(m, CMD_FORWARD);
     return first_failure(m, "s2d_multi_forward");
 }
@@ -899,20 +997,12 @@ int s2d_multi_forward(s2d_multi* m)
 int s2d_multi_get_image(s2d_multi* m, float* rgba32f)
 {
     if (!m || !rgba32f) return S2D_E_INVALID;
-    // every context returns a full-size image that is zero outside its slab: take each one's rows
-    std::vector<float> tmp;
+    DeviceGuard guard;
+    // every context holds (and returns) its own rows; together they tile the image
     const size_t row = (size_t)m->W * 4;
-    for (int r = 0; r < m->world; r++) {
-        float* dst = rgba32f;
-        if (r > 0) {
-            tmp.resize(row * (size_t)m->H);
-            dst = tmp.data();
-        }
-        if (int rc = s2d_get_image(m->ctx[(size_t)r], dst)) return mfail(m, rc, "s2d_get_image on rank %d: %s", r, s2d_last_error(m->ctx[(size_t)r]));
-        if (r > 0)
-            std::memcpy(rgba32f + row * (size_t)m->row_begin[(size_t)r], tmp.data() + row * (size_t)m->row_begin[(size_t)r],
-                        row * (size_t)(m->row_end[(size_t)r] - m->row_begin[(size_t)r]) * sizeof(float));
-    }
+    for (int r = 0; r < m->world; r++)
+        if (int rc = s2d_get_image_rows(m->ctx[(size_t)r], rgba32f + row * (size_t)m->row_begin[(size_t)r]))
+            return mfail(m, rc, "s2d_get_image_rows on rank %d: %s", r, s2d_last_error(m->ctx[(size_t)r]));
     return S2D_OK;
 }
 

@@ -204,16 +204,19 @@ __device__ __forceinline__ uint2 pack_half4(float4 c)
     return v;
 }
 
+// image_ref holds rows [row_begin, row_end) of the image (the context's slab).
 template <bool HALF>
-__global__ __launch_bounds__(256) void synthetic_target_kernel(void* __restrict__ image_ref, int W, int H)
+__global__ __launch_bounds__(256) void synthetic_target_kernel(void* __restrict__ image_ref, int W, int H, int row_begin,
+                                                               int row_end)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    const int y = blockIdx.y;
-    if (x >= W || y >= H) return;
+    const int y = row_begin + (int)blockIdx.y;
+    if (x >= W || y >= row_end) return;
     const float fx = (float)x / (float)W;
     const float4 c = make_float4(fx, 1.0f - fx, (float)y / (float)H, 1.0f);
-    if (HALF) reinterpret_cast<uint2*>(image_ref)[(size_t)y * W + x] = pack_half4(c);
-    else reinterpret_cast<float4*>(image_ref)[(size_t)y * W + x] = c;
+    const size_t at = (size_t)(y - row_begin) * W + x;
+    if (HALF) reinterpret_cast<uint2*>(image_ref)[at] = pack_half4(c);
+    else reinterpret_cast<float4*>(image_ref)[at] = c;
 }
 
 __global__ __launch_bounds__(256) void convert_f32_to_f16_kernel(const float4* __restrict__ src, uint2* __restrict__ dst,
@@ -261,12 +264,13 @@ hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t
     return hipGetLastError();
 }
 
-hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, hipStream_t stream)
+hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, int row_begin, int row_end, hipStream_t stream)
 {
+    const dim3 grid((W + 255) / 256, row_end - row_begin);
     if (half_images)
-        hipLaunchKernelGGL(synthetic_target_kernel<true>, dim3((W + 255) / 256, H), dim3(256), 0, stream, image_ref, W, H);
+        hipLaunchKernelGGL(synthetic_target_kernel<true>, grid, dim3(256), 0, stream, image_ref, W, H, row_begin, row_end);
     else
-        hipLaunchKernelGGL(synthetic_target_kernel<false>, dim3((W + 255) / 256, H), dim3(256), 0, stream, image_ref, W, H);
+        hipLaunchKernelGGL(synthetic_target_kernel<false>, grid, dim3(256), 0, stream, image_ref, W, H, row_begin, row_end);
     return hipGetLastError();
 }
 

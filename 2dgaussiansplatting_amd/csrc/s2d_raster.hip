@@ -142,7 +142,7 @@ __device__ __forceinline__ int stage_masks(uint32_t* s_mask32, int se, int sub, 
 // ---------------------------------------------------------------------------------------------------
 // EXACT (S2D_CFG_EXACT_EXP): G = expf(-d2/2) instead of exp_approx -- the switch the reference keeps at main.cpp:51
 // "for numerical varidation": the analytic gradients are those of the TRUE exponential, so only in this mode is the
-// backward pass the derivative of the forward pass (tests/test_gpu_fd.py checks exactly that by finite differences).
+// backward pass the derivative of the forward pass (tests/test_fd_end_to_end.py checks exactly that by finite differences).
 template <bool EXACT>
 __device__ __forceinline__ float gauss_of(float d2, bool* nonzero)
 {
@@ -179,6 +179,9 @@ __device__ __forceinline__ TileCtx tile_ctx(int tile, const Geometry& g)
     c.pxy = mk2((float)c.x + 0.5f, (float)c.y + 0.5f);
     return c;
 }
+
+// Where the thread's pixel sits in image0 / imageRef: the context stores only the rows of its slab.
+__device__ __forceinline__ size_t pixel_index(const TileCtx& c, const Geometry& g) { return (size_t)(c.y - g.row_begin) * g.W + c.x; }
 
 // LDS of the forward walk: per-entry record, three 16-B rows at one LDS address (one address register for the blend
 // loop's reads):  [0] pos.x, pos.y, a, b   [1] b, d, col_r, col_g   [2] col_b, opacity, -, -
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(256) void raster_forward_kernel(const uint32_t* __r
     f2 crg;
     float cb;
     forward_tile<COUNT, EXACT>(s, c, tile_off, list, proj, wave_masks, g, counters, crg, cb);
-    if (c.inside) store_pixel<HALF>(image0, (size_t)c.y * g.W + c.x, make_float4(crg.x, crg.y, cb, 1.0f)); // .w reset, main.cpp:543-546
+    if (c.inside) store_pixel<HALF>(image0, pixel_index(c, g), make_float4(crg.x, crg.y, cb, 1.0f)); // .w reset, main.cpp:543-546
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -688,8 +691,8 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
     const TileCtx c = tile_ctx(tile, g);
     float4 fin = make_float4(0.f, 0.f, 0.f, 0.f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
     if (c.inside) {
-        fin = load_pixel<HALF>(image0, (size_t)c.y * g.W + c.x);    // finalColor, main.cpp:613
-        ref = load_pixel<HALF>(image_ref, (size_t)c.y * g.W + c.x);
+        fin = load_pixel<HALF>(image0, pixel_index(c, g));    // finalColor, main.cpp:613
+        ref = load_pixel<HALF>(image_ref, pixel_index(c, g));
     }
     backward_tile<COUNT, NEED_OP, DET, EXACT>(s, c, fin, ref, tile_off, list, proj, wave_masks, grads, tile_sqerr, g, det, counters,
                                               SqerrJob{nullptr, 0, nullptr, nullptr});
@@ -729,8 +732,8 @@ __global__ __launch_bounds__(256) void raster_fused_kernel(const uint32_t* __res
         fin = make_float4(fa.x, fa.y, fb.x, fb.y);
     }
     if (c.inside) {
-        if (write_image) store_pixel<HALF>(image0, (size_t)c.y * g.W + c.x, fin); // .w reset, main.cpp:543-546
-        ref = load_pixel<HALF>(image_ref, (size_t)c.y * g.W + c.x);
+        if (write_image) store_pixel<HALF>(image0, pixel_index(c, g), fin); // .w reset, main.cpp:543-546
+        ref = load_pixel<HALF>(image_ref, pixel_index(c, g));
     } else {
         fin = make_float4(0.f, 0.f, 0.f, 0.f);
     }

@@ -124,11 +124,18 @@ def main():
     ap.add_argument("--rebin-interval", type=int, default=0)
     ap.add_argument("--fp16-images", action="store_true",
                     help="BASELINE configs[4] 'fp16 colour / fp32 grads': framebuffer and target held as 4 x fp16 per pixel")
+    ap.add_argument("--full-gradient", dest="full_gradient", action="store_true", default=None,
+                    help="after the timed block, time the same steps again with dL/d(opacity) accumulated too (main.cpp:703-704; "
+                         "the timed block leaves it out: with optimizeOpacity off, main.cpp:317, Adam never reads it) and report "
+                         "iterations_per_s_full_gradient beside value.  Default: on for one GPU")
+    ap.add_argument("--no-full-gradient", dest="full_gradient", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--exchange", default="halo", choices=["halo", "dense"],
-                    help="N > 1: 'halo' = slab ownership, ranks exchange gradient rows of boundary splats only "
-                         "(distributed.HaloStep); 'dense' = replicated state, all-reduce of all N x 9 gradients")
+    ap.add_argument("--exchange", default=None, choices=["halo", "dense"],
+                    help="N > 1: 'halo' (default) = slab ownership, ranks exchange gradient rows of boundary splats only "
+                         "(distributed.HaloStep); 'dense' = replicated state, all-reduce of all N x 9 gradients.  Left to the "
+                         "default, a failing all_to_all self-test switches to 'dense' (and the JSON says so); given by name, "
+                         "it ends the run with exit code 3 instead")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                     "to rehearse the multi-process path with several ranks sharing one GPU)")
     ap.add_argument("--launch-selftest", action="store_true",
@@ -202,10 +209,18 @@ def main():
     t.set_target_synthetic()
     t.init()
 
-    exchange = args.exchange if use_dist else "none"
+    exchange_requested = args.exchange or "halo"
+    exchange = exchange_requested if use_dist else "none"
     if exchange == "halo" and not D.all_to_all_selftest(dist, "cuda"):
-        # the collective pattern slab ownership needs misbehaved on this stack: every rank agreed (all-reduce) to
-        # use the replicated-state scheme instead -- slower, same results
+        # the collective pattern slab ownership needs misbehaved on this stack (every rank agreed on that: all-reduce)
+        if args.exchange == "halo":
+            # asked for by name: a scaling curve must not change scheme between two values of N without anybody noticing
+            if rank == 0:
+                print("bench.py: --exchange halo was requested and its all_to_all self-test failed on this stack", file=sys.stderr)
+            if dist is not None:
+                dist.destroy_process_group()
+            sys.exit(3)
+        # default scheme: use the replicated-state one instead -- slower, same results; the JSON line names both
         if rank == 0:
             print("bench.py: all_to_all self-test failed, falling back to --exchange dense", file=sys.stderr)
         exchange = "dense"
@@ -259,6 +274,43 @@ def main():
     torch.cuda.synchronize()
     psnr_iter = 199 if done + extra - 200 < 60000 else done + extra - 1
     sq200 = torch.from_numpy(t.sqerr_trace(psnr_iter, 1)).cuda()
+    # The whole backward pass of north_star -- dL/dpos, dL/dSigma, dL/dcolour AND dL/dopacity (main.cpp:703-704) -- timed
+    # the same way in a block of its own, outside `value`: the trajectory is the same (Adam reads dSplats.opacity only with
+    # "Optimize opacity" on, main.cpp:735), the raster kernel is its NEED_OP = true instantiation.
+    full = None
+    want_full = args.full_gradient if args.full_gradient is not None else world == 1
+    if want_full and args.steps > 0:
+        t.lean_backward = False
+        for _ in range(min(args.warmup, 5)):
+            one_step()
+        fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        fmarks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        freb = []
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        f0 = time.perf_counter()
+        for k in range(args.steps):
+            fmarks[k].record(stream)
+            before = t.rebuild_count()
+            one_step(fev[k])
+            freb.append(t.rebuild_count() != before)
+        fmarks[args.steps].record(stream)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        fdt = torch.tensor([time.perf_counter() - f0], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(fdt, op=dist.ReduceOp.MAX)
+        t.lean_backward = True
+        freb = np.array(freb, dtype=bool)
+        fstep = np.array([fmarks[k].elapsed_time(fmarks[k + 1]) for k in range(args.steps)], dtype=np.float64)
+        fk = np.array([a.elapsed_time(b) for a, b in fev], dtype=np.float64)
+        fk = fk[~freb] if (~freb).any() else fk
+        fsteady = fstep[~freb] if (~freb).any() else fstep
+        full = {"iterations_per_s": args.steps / float(fdt.item()), "ms_per_step": 1e3 * float(fdt.item()) / args.steps,
+                "iterations_per_s_median": 1e3 / float(np.median(fstep)), "iterations_per_s_steady_state": 1e3 / float(fsteady.mean()),
+                "steps_with_list_rebuild": int(freb.sum()), "kernel_ms": float(fk.mean()), "steps": args.steps}
     if dist is not None and sq200 is not None:
         D.reduce_sqerr(sq200, dist)
     sq = torch.from_numpy(t.sqerr_trace(first, args.steps)).cuda()
@@ -322,6 +374,12 @@ def main():
             "iterations_per_s_median": (1e3 / float(np.median(step_ms))) if args.steps else None,
             "iterations_per_s_steady_state": (1e3 / float(steady.mean())) if args.steps else None,
             "steps_with_list_rebuild": int(rebuilds.sum()),
+            # the same steps with dL/d(opacity) accumulated as well (the ninth gradient of main.cpp:703-704, which `value`'s
+            # block leaves out because nothing reads it while "Optimize opacity" is off): a block of its own, timed the same way
+            "iterations_per_s_full_gradient": full["iterations_per_s"] if full else None,
+            "full_gradient": full,
+            "backward_in_value": "dL/dpos, dL/dsx, dL/dsy, dL/drot, dL/dcolour (8 of the 9 gradients; dL/dopacity is unused while "
+                                 "optimizeOpacity is off, main.cpp:317,735)",
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
@@ -334,7 +392,9 @@ def main():
                        "width": W, "height": H, "n_splats": n,
                        "parallelism": "rowslab%d%s" % (world, ("+%s-%s" % ("rccl" if args.backend == "nccl" else args.backend,
                                                                               "halo-exchange" if exchange == "halo" else "allreduce-grads")) if use_dist else ""),
-                       "rebin_interval": args.rebin_interval},
+                       "rebin_interval": args.rebin_interval,
+                       "exchange_requested": (exchange_requested + ("" if args.exchange else " (default)")) if use_dist else "none",
+                       "exchange": exchange},
             "mse_last": mse_last,
             "psnr_db_last": (10.0 * float(np.log10(255.0 ** 2 / mse_last)) if mse_last > 0 else None),
             "psnr_db_at_iteration": psnr_iter,

@@ -36,7 +36,11 @@
 extern "C" {
 #endif
 
-#define S2D_ABI_VERSION 1
+/* Bumped whenever a struct that crosses the boundary changes layout or an entry point changes meaning; added entry points
+ * alone do not bump it.  s2d_abi_version() returns the value the LIBRARY was built with: a caller compares it with this
+ * macro before anything else (the Python binding does, load_library()).
+ *   2: s2d_stats starts with struct_size (round 2 had grown the struct in place under version 1). */
+#define S2D_ABI_VERSION 2
 
 /* == struct Splat, main.cpp:85-93 (vec2 pos; float sx, sy, rot; vec3 color; float opacity): 36 bytes.
  * Also the gradient record (dSplats, main.cpp:550). */
@@ -124,6 +128,8 @@ typedef struct s2d_config {
 } s2d_config;
 
 typedef struct s2d_stats {
+    uint32_t struct_size;      /* IN: sizeof(s2d_stats) as the caller was compiled; s2d_get_stats writes no more than that */
+    uint32_t reserved;
     uint64_t pairs_binned;     /* (tile, splat) pairs in the current tile lists */
     uint64_t pairs_capacity;
     uint64_t rebins;           /* times the tile lists were rebuilt */
@@ -148,7 +154,9 @@ int s2d_abi_version(void);
 int s2d_create(const s2d_config* cfg, s2d_ctx** out);
 void s2d_destroy(s2d_ctx* ctx);
 
-/* imageRef (main.cpp:254-259): width*height RGBA32F, row-major, .rgb in [0,1]; copied. */
+/* imageRef (main.cpp:254-259): width*height RGBA32F, row-major, .rgb in [0,1]; copied.  A slab context
+ * (row_begin/row_end) is handed the same full-size buffer and uploads and keeps only its own rows: device memory for
+ * imageRef and image0 is (row_end - row_begin) * width pixels each. */
 int s2d_set_target(s2d_ctx* ctx, const float* rgba32f);
 /* Fills imageRef on the device with ref(x,y) = (x/W, 1 - x/W, y/H, 1): the reference's commented generator
  * (main.cpp:261-267) plus a blue ramp, evaluated in fp32. */
@@ -166,6 +174,9 @@ int s2d_get_adam(s2d_ctx* ctx, s2d_splat_adam* adams, float* beta1t, float* beta
 int s2d_forward(s2d_ctx* ctx);
 /* image0 as uploaded at main.cpp:794: width*height RGBA32F, .w = 1.  Rows outside the slab are returned as 0. */
 int s2d_get_image(s2d_ctx* ctx, float* rgba32f);
+/* The slab's rows of image0 alone: (row_end - row_begin) * width RGBA32F, first row = row_begin (what a multi-GPU host
+ * stitches together; s2d_get_image of a whole-image context returns the same bytes). */
+int s2d_get_image_rows(s2d_ctx* ctx, float* rgba32f_rows);
 
 /* Backward pass, main.cpp:548-712: accumulates this slab's contribution into the gradient buffer
  * (which s2d_adam_step / s2d_step re-zero after use, like main.cpp:550).  Needs s2d_forward first. */
@@ -215,7 +226,8 @@ int s2d_rows_scatter(s2d_ctx* ctx, int32_t what, const int32_t* ids_device, int3
 int s2d_grads_combine(s2d_ctx* ctx, const int32_t* rows_device, int32_t n_rows, const int32_t* src_device, int32_t world,
                       const float* recv_device);
 
-/* ---- multi-GPU plumbing (one process per GPU; the host all-reduces between backward and Adam) ---- */
+/* ---- multi-GPU plumbing (one process per GPU; the caller's collective runs between s2d_forward_backward and
+ * s2d_adam_step, on the context's stream) ---- */
 /* Use caller-owned DEVICE memory (n_splats * 9 floats, layout s2d_splat[n]) as the gradient buffer, so the host
  * can all-reduce it in place (RCCL).  NULL -> back to the context's own buffer.  The buffer must be 16-byte
  * aligned, zero when bound, and is re-zeroed by s2d_adam_step. */
@@ -272,21 +284,11 @@ int s2d_multi_get_image(s2d_multi* m, float* rgba32f);
  * ranks), state rows handed over so far, splats held summed over the ranks (n_splats * n_devices when replicated). */
 int s2d_multi_exchange_info(s2d_multi* m, int64_t* out4);
 
+/* out->struct_size must be set by the caller (S2D_E_INVALID when it is smaller than the first version of the struct). */
 int s2d_get_stats(s2d_ctx* ctx, s2d_stats* out);
 /* s2d_stats.rebins without the device round trip s2d_get_stats makes (a host-side counter; never synchronises). */
 int s2d_get_rebuild_count(const s2d_ctx* ctx, uint64_t* rebuilds);
 const char* s2d_last_error(const s2d_ctx* ctx);
-
-/* ---- test hooks (used by tests/ through this ABI; not part of the training path) ---- */
-/* Device trig used by the projection kernel, evaluated on the GPU for n host floats. */
-int s2d_test_sincos(int32_t device, const float* x, int32_t n, float* sin_out, float* cos_out);
-/* Stable LSD radix sort of (key, value) pairs by the low `key_bits` bits of key, on the GPU. */
-int s2d_test_sort_pairs(int32_t device, uint32_t* keys, uint32_t* values, int64_t n, int32_t key_bits);
-/* Exclusive prefix sum on the GPU; returns the total in *total. */
-int s2d_test_exclusive_scan(int32_t device, uint32_t* data, int64_t n, uint64_t* total);
-/* The tile lists the raster kernels walk, for inspection: offsets has tiles+1 entries. */
-int s2d_debug_get_tile_lists(s2d_ctx* ctx, int32_t* tiles_x, int32_t* tiles_y, uint32_t* offsets,
-                             int64_t offsets_capacity, uint32_t* list, int64_t list_capacity);
 
 #ifdef __cplusplus
 }

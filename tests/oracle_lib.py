@@ -242,7 +242,13 @@ def grad_bars(got, w32, dsum, dabs, rel=1e-4):
     assert a <= 1e-6, a                             # (a) the exact sum to fp32 summation accuracy
     assert a <= b_ref, (a, b_ref)                   # (b) at least as close to it as the reference's own fp32 sum
     assert c <= rel, c                              # (c) 1e-4 against the oracle wherever the sum keeps >= 2 % of its terms
-    return {"a_gpu_vs_exact": a, "b_ref_vs_exact": b_ref, "c_gpu_vs_oracle": c}
+    # measured, not asserted: north_star's literal "1e-4 rel" -- the share of scalars whose GPU sum is within 1e-4 of the
+    # oracle's fp32 sum, and the share of the ORACLE's fp32 sums within 1e-4 of the exact (double) sum of the same terms
+    lit_gpu = float((np.abs(g - w)[nz] <= rel * np.abs(w[nz])).mean())
+    lit_ref = float((np.abs(w - dsum)[nz] <= rel * np.abs(dsum[nz])).mean())
+    lit_gpu_exact = float((np.abs(g - dsum)[nz] <= rel * np.abs(dsum[nz])).mean())
+    return {"a_gpu_vs_exact": a, "b_ref_vs_exact": b_ref, "c_gpu_vs_oracle": c, "literal_1e-4_gpu_vs_oracle_share": lit_gpu,
+            "literal_1e-4_oracle_vs_exact_share": lit_ref, "literal_1e-4_gpu_vs_exact_share": lit_gpu_exact}
 
 
 def ulp32(x):

@@ -5,6 +5,7 @@ import importlib
 import os
 import re
 import subprocess
+import sys
 import tempfile
 
 import pytest
@@ -13,6 +14,7 @@ import oracle_lib as O
 
 S2D = importlib.import_module("2dgaussiansplatting_amd")
 HEADER = os.path.join(O.ROOT, "include", "splat2d.h")
+TEST_HEADER = os.path.join(O.ROOT, "include", "splat2d_test.h")  # test / inspection hooks, outside the drop-in boundary
 
 
 @pytest.fixture(scope="module")
@@ -21,10 +23,12 @@ def lib():
     return S2D.load_library()
 
 
-def declared_symbols():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(s2d_[a-z0-9_]+)\s*\(", src)))
+def declared_symbols(headers=(HEADER, TEST_HEADER)):
+    names = set()
+    for h in headers:
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(s2d_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_every_declared_symbol_is_exported(lib):
@@ -32,8 +36,13 @@ def test_every_declared_symbol_is_exported(lib):
     assert len(names) >= 25
     for n in names:
         assert hasattr(lib, n), n
-    assert sorted(S2D.ABI_SYMBOLS) == names  # the binding's own list is the header's list
-    assert lib.s2d_abi_version() == 1
+    assert sorted(S2D.ABI_SYMBOLS) == names  # the binding's own list is the headers' list
+    # the product header holds no test hook, the test header nothing else
+    assert not [n for n in declared_symbols((HEADER,)) if n.startswith(("s2d_test_", "s2d_debug_"))]
+    assert all(n.startswith(("s2d_test_", "s2d_debug_")) for n in declared_symbols((TEST_HEADER,)))
+    # one version number: the header's macro, the library's answer, the binding's constant
+    macro = int(re.search(r"#define\s+S2D_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+    assert lib.s2d_abi_version() == macro == S2D.ABI_VERSION
 
 
 def test_struct_layouts_match_header():
@@ -147,3 +156,25 @@ def test_hip_sources_have_no_cuda_or_dual_path():
         txt = open(os.path.join(csrc, f)).read()
         for bad in ("__HIP_PLATFORM_AMD__", "cuda_runtime", "__CUDACC__", "hipify", "triton"):
             assert bad not in txt, (f, bad)
+
+
+@pytest.mark.parametrize("order", ["package_first", "torch_first"])
+def test_one_hip_runtime_whatever_the_import_order(order):
+    """torch's wheel bundles its own libamdhip64 (same SONAME, requested under another name), and
+    a process in which libsplat2d_hip.so came up first used to end with TWO runtimes mapped.  load_library() maps the
+    process's runtime first, so in a fresh process either import order leaves exactly one libamdhip64 image -- and
+    librccl, once torch has brought it, is the only one of its kind too."""
+    pytest.importorskip("torch")
+    load = ("import importlib; S = importlib.import_module('2dgaussiansplatting_amd'); L = S.load_library(); "
+            "assert L.s2d_abi_version() >= 1")
+    body = (load + "; import torch") if order == "package_first" else ("import torch; " + load)
+    code = ("import sys; sys.path.insert(0, %r); %s; "
+            "maps = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}); "
+            "rccl = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'librccl' in l}); "
+            "print(len(maps), len(rccl), maps, S.hip_runtimes_mapped() == maps)" % (O.ROOT, body))
+    env = {k: v for k, v in os.environ.items() if k != "S2D_HIP_RUNTIME"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    n_hip, n_rccl = r.stdout.split()[:2]
+    assert n_hip == "1" and n_rccl in ("0", "1"), r.stdout
+    assert r.stdout.strip().endswith("True")

@@ -83,9 +83,48 @@ def test_cfg4_row_slabs_tile_the_image(big):
             part = t.get_image()
             assert part[r0:r1].tobytes() == full_img[r0:r1].tobytes()
             assert not part[:r0].any() and not part[r1:].any()
+            assert t.get_image_rows().tobytes() == full_img[r0:r1].tobytes()   # the slab's rows alone
             assert t.stats()["pairs_binned"] < 0.3 * big.stats()["pairs_binned"]
             mse += t.mse()
     assert 0 < mse < full_mse
+
+
+def test_slab_context_stores_only_its_rows_of_the_images():
+    """imageRef and image0 (main.cpp:254, :310) of a slab context cover the slab's rows only: at 8192^2 a one-eighth slab
+    holds 2 x 134 MB instead of 2 x 1.07 GB.  Measured as the device's free memory (hipMemGetInfo) around s2d_create,
+    with few splats so that the images are what counts; the slab still renders its rows of the whole-image result."""
+    import torch
+    W = H = 8192
+    n = 4096
+    px_bytes = 16
+
+    def created_bytes(**kw):
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        t = S2D.Trainer(W, H, n, **kw)
+        t.synchronize()
+        return t, free0 - torch.cuda.mem_get_info()[0]
+
+    r0, r1 = D.slab_rows(H, 3, 8)
+    slab, b_slab = created_bytes(row_begin=r0, row_end=r1)
+    try:
+        whole, b_whole = created_bytes()
+        try:
+            saved = b_whole - b_slab
+            want = 2 * W * (H - (r1 - r0)) * px_bytes           # the rows the slab context no longer stores, twice
+            _report("slab_memory_8192_one_eighth", {"whole_context_MB": b_whole / 1e6, "slab_context_MB": b_slab / 1e6,
+                                                    "saved_MB": saved / 1e6, "expected_MB": want / 1e6})
+            assert saved >= 0.95 * want, (b_whole, b_slab, want)
+            assert b_slab <= 2 * W * (r1 - r0) * px_bytes + 64e6  # its two slabs of pixels + the small per-splat / per-tile arrays
+            for t in (whole, slab):
+                t.set_target_synthetic()
+                t.init()
+                t.forward()
+            assert slab.get_image_rows().tobytes() == whole.get_image()[r0:r1].tobytes()
+        finally:
+            whole.close()
+    finally:
+        slab.close()
 
 
 def test_cfg4_training_decreases_mse_and_respects_clamps():

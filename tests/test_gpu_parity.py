@@ -14,7 +14,13 @@ Bars (north_star: "within 1e-4 rel fp32"):
       (c) |gpu - oracle| <= 1e-4 * max(|oracle|, 0.02 * dabs)   1e-4 relative wherever the sum keeps >= 2 % of
                                                 its terms' magnitude; sums that cancel harder than 50:1 are
                                                 held to 2e-6 of the term magnitude instead (measured max 5e-5);
-  * one optimiser step from identical state: parameters within 1e-4 relative of the oracle's;
+      The literal "1e-4 of the result" is also MEASURED and reported (not asserted) for every case -- the share of gradient
+      scalars within 1e-4 of the oracle's value, next to the share of the ORACLE's own fp32 sums within 1e-4 of the exact
+      sum of its terms: sums that cancel cannot be held to 1e-4 of themselves by any fp32 summation order, the
+      reference's included (profiles/r03/r03_parity_report.txt);
+  * one optimiser step from identical state, judged on the UPDATE: |delta_gpu - delta_oracle| <= 1e-4 of lr per scalar
+    beyond one ulp of the parameter (oracle_lib.step_delta_error), and the parameters themselves within 1e-4 relative
+    (floor 1.0) of the oracle's;
   * MSE (double): 1e-9 relative for the same framebuffer.
 """
 import hashlib
@@ -1180,6 +1186,59 @@ def test_multi_device_handle_ownership_equals_replicated_state_bit_for_bit(world
     names = ["trace", "splats", "adam", "trace after set_splats", "splats after", "adam after"]
     for k, name in enumerate(names):
         assert out[False][k] == out[True][k], name
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_multi_device_handle_forward_after_new_splats_uses_fresh_hold_sets(world):
+    """step -> set_splats(other values) -> forward on a slab-ownership handle: the hold sets of the stepped run say
+    nothing about the new parameters, so s2d_multi_forward makes them afresh before it rasterises -- a splat that now
+    reaches a rank's rows without having been in its old set would otherwise be missing from that slab.  The stitched
+    image equals a single context's frame of the same splats bit for bit."""
+    W, H, n = 268, 213, 1500
+    tgt = mini_target()
+    with S2D.Trainer(W, H, n) as t:
+        t.set_target(tgt)
+        t.init()
+        first = t.get_splats()
+        # the new parameters: the init() splats in reverse order, so nearly every splat sits in other rows than before
+        new = first[::-1].copy()
+        t.set_splats(new)
+        t.forward()
+        want = t.get_image()
+    with S2D.MultiTrainer(W, H, n, [0] * world, share_gpu=True) as m:
+        m.set_target(tgt)
+        m.init()
+        m.step(70)                        # hold sets made, refreshed once at 64, every context now holds a subset
+        assert m.exchange_info()["held"] < n * world
+        m.set_splats(new)
+        m.forward()
+        got = m.get_image()
+        assert got.tobytes() == want.tobytes()
+        m.set_splats(first)               # ... and back, without a step in between
+        m.forward()
+        back = m.get_image()
+    with S2D.Trainer(W, H, n) as t:
+        t.set_target(tgt)
+        t.init()
+        t.forward()
+        assert back.tobytes() == t.get_image().tobytes()
+
+
+def test_backward_refuses_a_framebuffer_the_fused_launch_did_not_store():
+    """s2d_forward_backward with S2D_FB_SKIP_IMAGE leaves an OLDER frame in image0: a following s2d_backward, which reads
+    image0, must refuse (S2D_E_STATE) instead of differentiating against that frame; with the image stored it runs."""
+    o, t = make_pair(mini_target(), 1024, 2)
+    with t:
+        t.forward()
+        t.backward()
+        t.adam_step()
+        t.forward_backward(skip_image=True)
+        with pytest.raises(S2D.S2DError) as ei:
+            t.backward()
+        assert ei.value.code == 5 and "s2d_forward" in str(ei.value)
+        t.forward_backward(skip_image=False)
+        t.backward()   # same parameters, image0 current: allowed (adds a second copy of the gradients)
+        t.synchronize()
 
 
 @pytest.mark.parametrize("replicated", [False, True])
