@@ -53,14 +53,17 @@ struct s2d_ctx {
     bool deterministic = false;                 // S2D_CFG_DETERMINISTIC
     float* d_det_data = nullptr;                // [pair capacity][9] per-(tile, splat) partial gradients
     uint32_t* d_det_stamp = nullptr;            // [pair capacity]
+    uint32_t* d_det_touched = nullptr;          // [n]: which of a splat's slots the current pass wrote (zero between passes)
     uint32_t det_epoch = 0;                     // stamps written so far (monotone; 0 = never)
     uint64_t pair_capacity = 0;
     uint32_t* d_tile_off = nullptr;
+    uint32_t* d_tile_first = nullptr; // per tile id (padded to a power of two): position of its first pair (last radix pass)
     uint32_t* d_list = nullptr; // == one of d_vals after the sort
     uint64_t pairs = 0;
     uint64_t rebins = 0;
     bool lists_valid = false;
     bool proj_fresh = false; // d_proj and d_status->rebin_needed describe the CURRENT parameters
+    hipEvent_t ev_total = nullptr; // recorded behind the copy of the pair count to the host (rebuild_lists)
     hipEvent_t ev_flag = nullptr;  // recorded behind the kernel that ran the latest containment check
     int check_seq = 1;             // its sequence number (both stamp words start at 0: nothing matches before a check): the stamp that kernel writes if a splat left its rectangle
     int* h_rebin_stamp = nullptr;  // host-mapped copy of that stamp (written by the kernel, read after ev_flag)
@@ -170,7 +173,7 @@ int ensure_pair_capacity(s2d_ctx* c, uint64_t need)
     S2D_HIP(c, dev_alloc(&c->d_sort_temp, sort_temp_words((int64_t)cap)));
     S2D_HIP(c, dev_alloc(&c->d_wave_masks, (size_t)cap * 4));
     if (c->deterministic) {
-        S2D_HIP(c, dev_alloc(&c->d_det_data, (size_t)cap * 9));
+        S2D_HIP(c, dev_alloc(&c->d_det_data, (size_t)cap * kDetStride));
         S2D_HIP(c, dev_alloc(&c->d_det_stamp, (size_t)cap));
         S2D_HIP(c, hipMemsetAsync(c->d_det_stamp, 0, (size_t)cap * sizeof(uint32_t), c->stream));
     }
@@ -182,20 +185,39 @@ int ensure_pair_capacity(s2d_ctx* c, uint64_t need)
 int rebuild_lists(s2d_ctx* c)
 {
     const int n = c->n;
-    S2D_HIP(c, exclusive_scan_u32(c->d_counts, c->d_offsets, n, c->d_scan_temp, c->d_total, c->stream));
-    S2D_HIP(c, hipMemcpyAsync(c->h_total, c->d_total, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    S2D_HIP(c, hipStreamSynchronize(c->stream));
-    const uint64_t total = *c->h_total; // saturates at 0xFFFFFFFF instead of wrapping (scan_top_kernel)
-    if (total >= 0xFFFF0000ull)
-        return fail(c, S2D_E_NOMEM, "tile lists need more than 2^32 - 65536 (tile, splat) pairs");
-    int rc = ensure_pair_capacity(c, total);
-    if (rc != S2D_OK) return rc;
+    // the scan's last kernel stores the pair count into host-mapped memory itself (no copy engine between two kernels)
+    S2D_HIP(c, exclusive_scan_u32(c->d_counts, c->d_offsets, n, c->d_scan_temp, c->d_total, c->stream, c->h_total));
+    S2D_HIP(c, hipEventRecord(c->ev_total, c->stream));
+    // The pair emission needs the offsets, not the total (it never writes past the buffers' capacity): queue it behind the
+    // scan and wait for the SCAN only, so the host reads the total and queues the sort while the emission runs instead of
+    // the device idling through the host's round trip (~30 us per rebuild).  Only when the pairs outgrow the buffers
+    // (rare: they are sized with a quarter to spare) is the emission queued again.
     S2D_HIP(c, launch_emit_pairs(c->d_rects, c->d_offsets, c->d_counts, n, c->g, c->d_keys[0], c->d_vals[0],
                                  (uint32_t)c->pair_capacity, c->stream));
+    S2D_HIP(c, hipEventSynchronize(c->ev_total));
+    const uint64_t total = *(volatile uint32_t*)c->h_total; // saturates at 0xFFFFFFFF instead of wrapping (scan_top_kernel)
+    if (total >= 0xFFFF0000ull)
+        return fail(c, S2D_E_NOMEM, "tile lists need more than 2^32 - 65536 (tile, splat) pairs");
+    if (total > c->pair_capacity) {
+        int rc = ensure_pair_capacity(c, total);
+        if (rc != S2D_OK) return rc;
+        S2D_HIP(c, launch_emit_pairs(c->d_rects, c->d_offsets, c->d_counts, n, c->g, c->d_keys[0], c->d_vals[0],
+                                     (uint32_t)c->pair_capacity, c->stream));
+    }
     uint32_t *k_out = nullptr, *v_out = nullptr;
-    S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)total,
-                              key_bits_for(c->g.num_tiles), c->d_sort_temp, &k_out, &v_out, c->stream));
-    S2D_HIP(c, launch_tile_offsets(k_out, (uint32_t)total, c->g.num_tiles, c->d_tile_off, c->stream));
+    const int key_bits = key_bits_for(c->g.num_tiles);
+    if (key_bits > 0) {
+        // the last radix pass records where each tile's pairs begin instead of writing the sorted keys out
+        S2D_HIP(c, hipMemsetAsync(c->d_tile_first, 0xFF, ((size_t)1 << key_bits) * sizeof(uint32_t), c->stream));
+        S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)total, key_bits,
+                                  c->d_sort_temp, &k_out, &v_out, c->d_tile_first, c->stream));
+        S2D_HIP(c, launch_tile_offsets_from_first(c->d_tile_first, c->g.num_tiles, (uint32_t)total,
+                                                  c->d_tile_first + ((size_t)1 << key_bits), c->d_tile_off, c->stream));
+    } else { // a single tile: nothing to sort
+        S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)total, key_bits,
+                                  c->d_sort_temp, &k_out, &v_out, nullptr, c->stream));
+        S2D_HIP(c, launch_tile_offsets(k_out, (uint32_t)total, c->g.num_tiles, c->d_tile_off, c->stream));
+    }
     c->d_list = v_out;
     c->pairs = total;
     c->rebins++;
@@ -225,7 +247,7 @@ int launch_raster(s2d_ctx* c, bool optimistic, const RasterJob& job)
     DetGather dg{};
     if (c->deterministic) {
         c->det_epoch++; // a fresh stamp per backward pass (slots of earlier passes become invalid)
-        dg = DetGather{c->d_rects, c->d_offsets, c->d_counts, c->d_det_data, c->d_det_stamp, c->det_epoch, c->n};
+        dg = DetGather{c->d_rects, c->d_offsets, c->d_counts, c->d_det_data, c->d_det_stamp, c->d_det_touched, c->det_epoch, c->n};
     }
     S2D_HIP(c, launch_raster_fused(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->half_images, c->d_wave_masks,
                                    c->d_grads, c->d_tile_sqerr, c->g, job.need_opacity_grad, c->deterministic ? &dg : nullptr,
@@ -302,7 +324,7 @@ int queue_backward(s2d_ctx* c, bool need_opacity_grad)
     DetGather dg{};
     if (c->deterministic) {
         c->det_epoch++; // a fresh stamp per backward pass (slots of earlier passes become invalid)
-        dg = DetGather{c->d_rects, c->d_offsets, c->d_counts, c->d_det_data, c->d_det_stamp, c->det_epoch, c->n};
+        dg = DetGather{c->d_rects, c->d_offsets, c->d_counts, c->d_det_data, c->d_det_stamp, c->d_det_touched, c->det_epoch, c->n};
     }
     S2D_HIP(c, launch_raster_backward(c->d_tile_off, c->d_list, c->d_proj, c->d_image0, c->d_ref, c->half_images,
                                       c->d_wave_masks, c->d_grads,
@@ -479,7 +501,12 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, dev_alloc(&c->d_scan_temp, scan_temp_words((int64_t)n)));
     S2D_HIP(c, dev_alloc(&c->d_total, 4));
     S2D_HIP(c, dev_alloc(&c->d_tile_off, (size_t)g.num_tiles + 1));
+    S2D_HIP(c, dev_alloc(&c->d_tile_first, ((size_t)1 << key_bits_for(g.num_tiles)) + tile_first_temp_words(g.num_tiles))); // + chunk minima
     c->deterministic = (cfg->flags & S2D_CFG_DETERMINISTIC) != 0;
+    if (c->deterministic) {
+        S2D_HIP(c, dev_alloc(&c->d_det_touched, n));
+        S2D_HIP(c, hipMemset(c->d_det_touched, 0, n * sizeof(uint32_t)));
+    }
     c->half_images = (cfg->flags & S2D_CFG_FP16_IMAGES) != 0;
     c->pixel_bytes = c->half_images ? 8 : sizeof(float4);
     S2D_HIP(c, hipMalloc(&c->d_image0, px * c->pixel_bytes));
@@ -490,7 +517,8 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, dev_alloc(&c->d_status, 1));
     S2D_HIP(c, dev_alloc(&c->d_counters, 1));
     S2D_HIP(c, hipEventCreateWithFlags(&c->ev_flag, hipEventDisableTiming));
-    S2D_HIP(c, hipHostMalloc((void**)&c->h_total, 64, hipHostMallocDefault));
+    S2D_HIP(c, hipEventCreateWithFlags(&c->ev_total, hipEventDisableTiming));
+    S2D_HIP(c, hipHostMalloc((void**)&c->h_total, 64, hipHostMallocMapped));
     S2D_HIP(c, hipHostMalloc((void**)&c->h_status, sizeof(DeviceStatus), hipHostMallocDefault));
     S2D_HIP(c, hipHostMalloc((void**)&c->h_trace, kHostTrace * sizeof(double), hipHostMallocDefault));
     S2D_HIP(c, hipHostMalloc((void**)&c->h_rebin_stamp, 64, hipHostMallocMapped));
@@ -520,11 +548,12 @@ void s2d_destroy(s2d_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         void* ptrs[] = {c->d_splats, c->d_adams, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
-                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_tile_off, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work, c->d_sqerr_trace,
+                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_det_touched, c->d_tile_off, c->d_tile_first, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work, c->d_sqerr_trace,
                         c->d_status, c->d_counters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (c->ev_flag) (void)hipEventDestroy(c->ev_flag);
+        if (c->ev_total) (void)hipEventDestroy(c->ev_total);
         if (c->h_total) (void)hipHostFree(c->h_total);
         if (c->h_status) (void)hipHostFree(c->h_status);
         if (c->h_trace) (void)hipHostFree(c->h_trace);
@@ -998,7 +1027,7 @@ int s2d_test_sort_pairs(int32_t device, uint32_t* keys, uint32_t* values, int64_
     S2D_HIP0(hipMalloc((void**)&temp, sort_temp_words(n) * sizeof(uint32_t)));
     S2D_HIP0(hipMemcpy(k[0], keys, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
     S2D_HIP0(hipMemcpy(v[0], values, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    S2D_HIP0(sort_pairs_u32(k[0], v[0], k[1], v[1], n, key_bits, temp, &ko, &vo, nullptr));
+    S2D_HIP0(sort_pairs_u32(k[0], v[0], k[1], v[1], n, key_bits, temp, &ko, &vo, nullptr, nullptr));
     S2D_HIP0(hipDeviceSynchronize());
     S2D_HIP0(hipMemcpy(keys, ko, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
     S2D_HIP0(hipMemcpy(values, vo, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));

@@ -135,15 +135,25 @@ constexpr int kScanItemsPerBlock = kScanBlock * kScanItemsPerThread; // 2048
 // ---- launchers (each queues kernels on `stream`, never synchronises) ------------------------------
 // scan / sort (s2d_scan_sort.hip)
 size_t scan_temp_words(int64_t n);
-// exclusive prefix sum of in[0..n) into out[0..n) (may alias); *total_dev (device) receives the sum.
+// exclusive prefix sum of in[0..n) into out[0..n) (may alias); *total_dev (device) receives the sum, and so does
+// *total_host_mapped (host memory mapped into the device's address space, written by the kernel itself: complete once an
+// event recorded behind this call has completed).
 hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* temp, uint32_t* total_dev,
-                              hipStream_t stream);
+                              hipStream_t stream, uint32_t* total_host_mapped = nullptr);
 size_t sort_temp_words(int64_t n);
 // Stable LSD radix sort by the low key_bits of keys.  Result pointers (one of the two buffers each) are
 // returned through keys_out / vals_out.
+// tile_first != nullptr (1 << key_bits words, all 0xFFFFFFFF on entry): the last pass leaves the sorted KEYS unwritten and
+// records tile_first[k] = position of the first pair with key k instead (launch_tile_offsets_from_first turns that into
+// the list boundaries): one 4-byte stream less to write and none to read back.  key_bits == 0 sorts nothing: not for that.
 hipError_t sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int64_t n,
-                          int key_bits, uint32_t* temp, uint32_t** keys_out, uint32_t** vals_out,
+                          int key_bits, uint32_t* temp, uint32_t** keys_out, uint32_t** vals_out, uint32_t* tile_first,
                           hipStream_t stream);
+// tile_off[t] = first position with key >= t for t in [0, num_keys], from tile_first (see sort_pairs_u32);
+// temp: tile_first_temp_words(num_keys) words
+size_t tile_first_temp_words(int num_keys);
+hipError_t launch_tile_offsets_from_first(const uint32_t* tile_first, int num_keys, uint32_t total, uint32_t* temp,
+                                          uint32_t* tile_off, hipStream_t stream);
 
 // binning (s2d_binning.hip)
 // Projects every splat; mode 0: also writes rects[] (inflated by `margin` pixels) and counts[];
@@ -166,13 +176,16 @@ hipError_t launch_raster_forward(const uint32_t* tile_off, const uint32_t* list,
                                  hipStream_t stream);
 // Deterministic gradient accumulation (S2D_CFG_DETERMINISTIC): instead of float atomics every tile stores its
 // partial gradient of a splat into the slot offsets[splat] + (position of the tile in the splat's emission
-// rectangle), stamped with the iteration; a gather kernel then sums each splat's stamped slots in slot order.
+// rectangle), stamped with the iteration and announced in the splat's `touched` word; a gather kernel then sums each
+// splat's written slots in slot order.
+constexpr int kDetStride = 12; // floats per slot: nine gradients, padded so that a slot is three aligned 16-byte words
 struct DetGather {
     const TileRect* rects;
     const uint32_t* offsets;
     const uint32_t* counts;
-    float* data;      // [pair capacity][9]
+    float* data;      // [pair capacity][kDetStride]
     uint32_t* stamp;  // [pair capacity]
+    uint32_t* touched; // [n]: per splat, which of its slots were written in this pass (zero between passes)
     uint32_t now;     // iteration + 1 (never 0: 0 marks a slot that was never written)
     int n;
 };

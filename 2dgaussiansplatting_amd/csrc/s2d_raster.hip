@@ -419,29 +419,42 @@ __device__ __forceinline__ float div_by_recip(float num, float den, float r)
 // ---------------------------------------------------------------------------------------------------
 // Where a tile puts its partial gradient of a splat in deterministic mode.
 struct DetSlots {
-    const TileRect* rects;    // per splat: the rectangle its pairs were emitted from
-    const uint32_t* offsets;  // per splat: first emission slot
-    float* data;              // [pairs][9]
-    uint32_t* stamp;          // [pairs]: iteration + 1 of the last write
-    uint32_t now;             // iteration + 1
+    const TileRect* rects;     // per splat: the rectangle its pairs were emitted from
+    const uint32_t* offsets;   // per splat: first emission slot
+    float* data;               // [pairs][kDetStride]: nine floats per slot, padded to three 16-byte words
+    uint32_t* stamp;           // [pairs]: iteration + 1 of the last write
+    uint32_t* touched;         // [splats]: bit j = slot offsets[i] + j was written in this pass (bit 31: some slot >= 31)
+    uint32_t now;              // iteration + 1
 };
 
-// LDS of the backward walk.
+// LDS of the backward walk.  Entries per staged batch: 64, or 32 in deterministic mode, whose four per-wave slot sets would
+// otherwise lift the workgroup from 19.5 to 25.7 KB of LDS -- six instead of eight workgroups per CU, which alone costs
+// ~14 % (profiles/r03/r03_bound_experiments.txt); with half-size batches it is 17.5 KB.  The forward walk stages 64 either
+// way: the lane masks it leaves behind are indexed by list position, and a walk that looks at its pixels' throughput
+// every 32 entries stops no later than one that looks every 64.
 template <bool DET>
 struct BwdShared {
-    float4 q0[B]; // pos.x, pos.y, a, b
-    float4 q1[B]; // b, d, col_r, col_g
-    float4 q2[B]; // col_b, opacity, (sx^2-sy^2)/(sx^2 sy^2), sin*cos
-    float4 e0[B]; // cc, ss, 2sc, cc - ss
-    float4 e1[B]; // ss, cc, 1/sx^3, 1/sy^3
-    unsigned long long mask[4 * B]; // [wave][entry]
+    static constexpr int kBatch = DET ? 32 : B;
+    float4 q0[kBatch]; // pos.x, pos.y, a, b
+    float4 q1[kBatch]; // b, d, col_r, col_g
+    float4 q2[kBatch]; // col_b, opacity, (sx^2-sy^2)/(sx^2 sy^2), sin*cos
+    float4 e0[kBatch]; // cc, ss, 2sc, cc - ss
+    float4 e1[kBatch]; // ss, cc, 1/sx^3, 1/sy^3
+    unsigned long long mask[4 * kBatch]; // [wave][entry]
     // Partial gradients of the batch, 9 floats per slot (+3 pad where one slot per entry is shared).  Deterministic mode:
     // one slot per wave, plain stores, summed over the 4 waves in a fixed order by the flush.  Otherwise the four waves add into ONE slot
     // per entry with ds_add_f32 (eight lanes, eight addresses per wave and entry): the order of those four
     // additions is as free as the order of the global atomics that follow, and 9 KB less LDS per workgroup is
     // one to two more resident workgroups per CU.  The flush zeroes what it read.
     static constexpr int kPartStride = DET ? 9 : 12; // floats per slot (deterministic mode packs its four slots per entry tightly)
-    __attribute__((aligned(16))) float part[(DET ? 4 : 1) * B * kPartStride];
+    __attribute__((aligned(16))) float part[(DET ? 4 : 1) * kBatch * kPartStride];
+    // Splat index of each staged entry: the flush addresses gradients without going back to the list.  Two copies, by batch
+    // parity: a batch's flush runs behind the last barrier of the batch, so fast threads already stage the NEXT batch
+    // (and overwrite these words) while slow ones still flush.  Deterministic mode also keeps the entry's slot for this
+    // tile and which of the splat's slots that is.
+    uint32_t idx[2][kBatch];
+    uint32_t slot[2][DET ? kBatch : 1];
+    uint32_t local[2][DET ? kBatch : 1];
     unsigned long long touched[4]; // bit e: wave w wrote slot e in this batch
     double red[4];
     int4 alive;                    // per wave: does it still have a live pixel (block_any_alive)
@@ -460,6 +473,7 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
                                               const Geometry& g, const DetSlots& det, PairCounters* __restrict__ counters,
                                               const SqerrJob& sq)
 {
+    constexpr int BB = BwdShared<DET>::kBatch; // entries per staged batch
     const int tid = c.tid, lane = c.lane, w = c.w;
     const bool inside = c.inside;
     const f2 pxy = c.pxy;
@@ -476,7 +490,7 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
         if (lane == 0) s.red[w] = e2;
     }
     if (!DET)
-        for (int i = tid; i < B * 3; i += 256) reinterpret_cast<float4*>(s.part)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < BB * 3; i += 256) reinterpret_cast<float4*>(s.part)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     if (sq.out == nullptr) {
         if (tid == 0) tile_sqerr[c.tile] = ((s.red[0] + s.red[1]) + s.red[2]) + s.red[3];
@@ -508,13 +522,21 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
 
     const uint32_t beg = tile_off[c.tile], end = tile_off[c.tile + 1];
     const int se = tid >> 2, sub = tid & 3;
-    for (uint32_t base = beg; base < end; base += B) {
-        const int cnt = (int)min((uint32_t)B, end - base);
+    for (uint32_t base = beg; base < end; base += BB) {
+        const int cnt = (int)min((uint32_t)BB, end - base);
+        const int pb = (int)(((base - beg) / (uint32_t)BB) & 1u); // which copy of the per-entry index words this batch uses
         if (se < cnt) {
             // the forward pass of this iteration staged the same batch and left its lane masks behind
-            s.mask[sub * B + se] = wave_masks[(size_t)(base + se) * 4 + sub];
+            s.mask[sub * BB + se] = wave_masks[(size_t)(base + se) * 4 + sub];
             if (sub == 0) {
                 const uint32_t idx = list[base + se];
+                s.idx[pb][se] = idx;
+                if (DET) { // the slot of this tile in the splat's emission rectangle (row-major), looked up beside the record
+                    const TileRect r = det.rects[idx];
+                    const uint32_t local = (uint32_t)(c.ty - g.trow0 - r.ty0) * (uint32_t)(r.tx1 - r.tx0 + 1) + (uint32_t)(c.tx - r.tx0);
+                    s.slot[pb][se] = det.offsets[idx] + local;
+                    s.local[pb][se] = min(local, 31u);
+                }
                 const ProjRec* r = proj + idx;
                 const float4 q0 = r->q0, q1 = r->q1, q2 = r->q2;
                 const float4 q3 = r->q3; // sin, 1/sx^3, 1/sy^3, (sx^2-sy^2)/(sx^2 sy^2): divided once per splat (pack_proj)
@@ -531,7 +553,7 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
         if (COUNT) n_staged += (tid == 0) ? (unsigned long long)cnt : 0ull;
         unsigned long long touched = 0ull;
         if (alive_mask != 0ull || COUNT) {
-            const unsigned long long my_mask = (lane < cnt) ? s.mask[w * B + lane] : 0ull;
+            const unsigned long long my_mask = (lane < cnt) ? s.mask[w * BB + lane] : 0ull;
             unsigned long long cand = __ballot(COUNT ? my_mask != 0ull : (my_mask & alive_mask) != 0ull); // as in the forward walk
             while (cand != 0ull) {
                 const int e = __builtin_ctzll(cand);
@@ -617,7 +639,7 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
                 // v_mad_u64_u32 in the blend loop.
                 float* const part = s.part;
                 int pe;
-                asm("s_mul_i32 %0, %1, %2" : "=s"(pe) : "s"((DET ? __builtin_amdgcn_readfirstlane(w) : 0) * B + e), "n"(BwdShared<DET>::kPartStride));
+                asm("s_mul_i32 %0, %1, %2" : "=s"(pe) : "s"((DET ? __builtin_amdgcn_readfirstlane(w) : 0) * BB + e), "n"(BwdShared<DET>::kPartStride));
                 if (DET) {
                     if ((lane & 7) == 0) part[pe + part_slot] = tot;
                     if (NEED_OP && lane == 63) part[pe + 8] = g_op;
@@ -640,7 +662,7 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
 #pragma unroll
                 for (int ww = 0; ww < (DET ? 4 : 1); ww++)
                     if ((s.touched[ww] >> e) & 1ull) {
-                        v += s.part[(ww * B + e) * BwdShared<DET>::kPartStride + k];
+                        v += s.part[(ww * BB + e) * BwdShared<DET>::kPartStride + k];
                         any_w = true;
                     }
             } else {
@@ -651,15 +673,15 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
             }
             if (DET) {
                 if (any_w) {
-                    const uint32_t idx = list[base + e];
-                    const TileRect r = det.rects[idx];
-                    const uint32_t slot = det.offsets[idx] + (uint32_t)(c.ty - g.trow0 - r.ty0) * (uint32_t)(r.tx1 - r.tx0 + 1) +
-                                          (uint32_t)(c.tx - r.tx0);
-                    det.data[(size_t)slot * 9 + k] = (!NEED_OP && k == 8) ? 0.0f : v;
-                    if (k == 0) det.stamp[slot] = det.now;
+                    const uint32_t slot = s.slot[pb][e];
+                    det.data[(size_t)slot * kDetStride + k] = (!NEED_OP && k == 8) ? 0.0f : v;
+                    if (k == 0) {
+                        det.stamp[slot] = det.now;
+                        atomicOr(det.touched + s.idx[pb][e], 1u << s.local[pb][e]); // which slots the gather pass has to read
+                    }
                 }
             } else if (any_w && v != 0.0f) {
-                atomicAdd(grads + (size_t)list[base + e] * 9 + k, v); // the index again from the list (an L2 hit)
+                atomicAdd(grads + (size_t)s.idx[pb][e] * 9 + k, v);
             }
         }
         if (!any) break;
@@ -706,7 +728,7 @@ __global__ __launch_bounds__(256) void raster_backward_kernel(const uint32_t* __
 // final colour as stored, i.e. rounded to fp16, exactly like the separate kernels.  image0 is written only when
 // `write_image` is set (s2d_step: the last iteration of the call; nothing else reads it).
 template <bool NEED_OP, bool HALF, bool DET, bool EXACT>
-__global__ __launch_bounds__(256) void raster_fused_kernel(const uint32_t* __restrict__ tile_off,
+__global__ __launch_bounds__(256, 8) void raster_fused_kernel(const uint32_t* __restrict__ tile_off,
                                                            const uint32_t* __restrict__ list,
                                                            const ProjRec* __restrict__ proj, void* __restrict__ image0,
                                                            const void* __restrict__ image_ref,
@@ -743,22 +765,64 @@ __global__ __launch_bounds__(256) void raster_fused_kernel(const uint32_t* __res
 }
 
 // Deterministic mode: gradient of splat i = sum of the partials its tiles stored this iteration, in emission
-// (tile row-major) order -- the same order whatever the dispatch order of the tiles was.
+// (tile row-major) order -- the same order whatever the dispatch order of the tiles was.  A splat's tiles announce
+// themselves in touched[i] (bit j = its j-th emission slot; a tile reaches a splat's entry only while some pixel of it is
+// still live, so most of a splat's ~20 slots stay unwritten and a hidden splat has none): the pass reads one word per
+// splat and then only the slots that hold something, instead of every stamp of every slot.  Slots from the 32nd on share
+// bit 31 and are told apart by their stamps.  The word is cleared for the next pass.
+__device__ __forceinline__ void det_add_slot(float (&acc)[9], const float* __restrict__ data, uint32_t slot)
+{
+    const float4* d = reinterpret_cast<const float4*>(data + (size_t)slot * kDetStride); // three 16-byte loads per slot
+    const float4 a = d[0], b = d[1], c = d[2];
+    acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+    acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+    acc[8] += c.x;
+}
+
 __global__ __launch_bounds__(256) void gather_grads_kernel(const uint32_t* __restrict__ offsets,
                                                            const uint32_t* __restrict__ counts, int n,
                                                            const float* __restrict__ data,
-                                                           const uint32_t* __restrict__ stamp, uint32_t now,
-                                                           float* __restrict__ grads)
+                                                           const uint32_t* __restrict__ stamp, uint32_t* __restrict__ touched,
+                                                           uint32_t now, float* __restrict__ grads)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    uint32_t m = touched[i];
+    if (m == 0u) return; // no tile wrote anything for this splat: its gradient record stays as it is (zero)
+    touched[i] = 0u;
     float acc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const uint32_t o = offsets[i], c = counts[i];
-    for (uint32_t s = o; s < o + c; s++) {
-        if (stamp[s] != now) continue;
-        const float* d = data + (size_t)s * 9;
+    const uint32_t o = offsets[i];
+    const bool tail = (m >> 31) != 0u;
+    m &= 0x7FFFFFFFu;
+    while (m != 0u) { // ascending slot order, four slots' loads in flight at a time
+        uint32_t js[4];
+        int cnt = 0;
 #pragma unroll
-        for (int k = 0; k < 9; k++) acc[k] += d[k];
+        for (int q = 0; q < 4; q++)
+            if (m != 0u) {
+                js[q] = (uint32_t)__builtin_ctz(m);
+                m &= m - 1u;
+                cnt = q + 1;
+            }
+        float4 v[4][3];
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q < cnt) {
+                const float4* d = reinterpret_cast<const float4*>(data + (size_t)(o + js[q]) * kDetStride);
+                v[q][0] = d[0]; v[q][1] = d[1]; v[q][2] = d[2];
+            }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (q < cnt) {
+                acc[0] += v[q][0].x; acc[1] += v[q][0].y; acc[2] += v[q][0].z; acc[3] += v[q][0].w;
+                acc[4] += v[q][1].x; acc[5] += v[q][1].y; acc[6] += v[q][1].z; acc[7] += v[q][1].w;
+                acc[8] += v[q][2].x;
+            }
+    }
+    if (tail) {
+        const uint32_t c = counts[i];
+        for (uint32_t s = o + 31u; s < o + c; s++)
+            if (stamp[s] == now) det_add_slot(acc, data, s);
     }
     float* gr = grads + (size_t)i * 9;
 #pragma unroll
@@ -807,8 +871,8 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
                                   PairCounters* counters, bool count, bool exact_exp, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
-    DetSlots det{nullptr, nullptr, nullptr, nullptr, 0u};
-    if (dg) det = DetSlots{dg->rects, dg->offsets, dg->data, dg->stamp, dg->now};
+    DetSlots det{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    if (dg) det = DetSlots{dg->rects, dg->offsets, dg->data, dg->stamp, dg->touched, dg->now};
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
 #define S2D_LAUNCH_BWD(C, O, H, D)                                                                                       \
     hipLaunchKernelGGL((raster_backward_kernel<C, O, H, D, false>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
@@ -832,7 +896,7 @@ hipError_t launch_raster_backward(const uint32_t* tile_off, const uint32_t* list
 #undef S2D_LAUNCH_BWD
     if (dg && dg->n > 0)
         hipLaunchKernelGGL(gather_grads_kernel, dim3((dg->n + 255) / 256), dim3(256), 0, stream, dg->offsets, dg->counts,
-                           dg->n, dg->data, dg->stamp, dg->now, grads);
+                           dg->n, dg->data, dg->stamp, dg->touched, dg->now, grads);
     return hipGetLastError();
 }
 
@@ -843,8 +907,8 @@ hipError_t launch_raster_fused(const uint32_t* tile_off, const uint32_t* list, c
                                SqerrJob sq, hipStream_t stream)
 {
     if (g.num_tiles <= 0) return hipSuccess;
-    DetSlots det{nullptr, nullptr, nullptr, nullptr, 0u};
-    if (dg) det = DetSlots{dg->rects, dg->offsets, dg->data, dg->stamp, dg->now};
+    DetSlots det{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    if (dg) det = DetSlots{dg->rects, dg->offsets, dg->data, dg->stamp, dg->touched, dg->now};
     const dim3 grid(raster_grid(g.num_tiles)), block(256);
     const int wi = write_image ? 1 : 0;
 #define S2D_LAUNCH_FUSED(O, H, D, X)                                                                                       \
@@ -862,7 +926,7 @@ hipError_t launch_raster_fused(const uint32_t* tile_off, const uint32_t* list, c
 #undef S2D_LAUNCH_FUSED
     if (dg && dg->n > 0)
         hipLaunchKernelGGL(gather_grads_kernel, dim3((dg->n + 255) / 256), dim3(256), 0, stream, dg->offsets, dg->counts,
-                           dg->n, dg->data, dg->stamp, dg->now, grads);
+                           dg->n, dg->data, dg->stamp, dg->touched, dg->now, grads);
     return hipGetLastError();
 }
 

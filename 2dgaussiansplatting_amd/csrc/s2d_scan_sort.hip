@@ -64,7 +64,8 @@ __global__ __launch_bounds__(kScanBlock) void scan_reduce_kernel(const uint32_t*
 }
 
 __global__ __launch_bounds__(kScanBlock) void scan_top_kernel(uint32_t* __restrict__ block_sums, int64_t nb,
-                                                              uint32_t* __restrict__ total_out)
+                                                              uint32_t* __restrict__ total_out,
+                                                              uint32_t* __restrict__ total_host)
 {
     __shared__ uint32_t s_wave[4];
     __shared__ unsigned long long s_wide[kScanBlock / 64];
@@ -86,10 +87,13 @@ __global__ __launch_bounds__(kScanBlock) void scan_top_kernel(uint32_t* __restri
     for (int d = 32; d >= 1; d >>= 1) wide += __shfl_down(wide, d, 64);
     if ((threadIdx.x & 63) == 0) s_wide[threadIdx.x >> 6] = wide;
     __syncthreads();
-    if (threadIdx.x == 0 && total_out) {
+    if (threadIdx.x == 0 && (total_out || total_host)) {
         unsigned long long all = 0;
         for (int k = 0; k < kScanBlock / 64; k++) all += s_wide[k];
-        *total_out = all > 0xFFFFFFFFull ? 0xFFFFFFFFu : carry;
+        const uint32_t total = all > 0xFFFFFFFFull ? 0xFFFFFFFFu : carry;
+        if (total_out) *total_out = total;
+        // host-mapped word: the host reads it behind an event recorded after this kernel, no copy engine in between
+        if (total_host) __hip_atomic_store(total_host, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -123,15 +127,16 @@ static inline int64_t scan_blocks(int64_t n) { return (n + kScanItemsPerBlock - 
 size_t scan_temp_words(int64_t n) { return (size_t)scan_blocks(n) + 4; }
 
 hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint32_t* temp, uint32_t* total_dev,
-                              hipStream_t stream)
+                              hipStream_t stream, uint32_t* total_host_mapped)
 {
     if (n <= 0) {
+        if (total_host_mapped) *total_host_mapped = 0u; // nothing is queued that could write it
         if (total_dev) return hipMemsetAsync(total_dev, 0, sizeof(uint32_t), stream);
         return hipSuccess;
     }
     const int64_t nb = scan_blocks(n);
     hipLaunchKernelGGL(scan_reduce_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, stream, in, n, temp);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(kScanBlock), 0, stream, temp, nb, total_dev);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(kScanBlock), 0, stream, temp, nb, total_dev, total_host_mapped);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nb), dim3(kScanBlock), 0, stream, in, out, n, temp);
     return hipGetLastError();
 }
@@ -158,12 +163,18 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t* 
     ghist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
 }
 
+// LAST (the pass of the highest digit, when the caller wants list boundaries instead of sorted keys): the keys are not
+// written out; instead tile_first[k] = position of the first pair of key k, by atomicMin over the blocks that hold pairs of
+// k.  A block's pairs of one digit leave it in input order (the sort is stable) and the input of the last pass is ordered
+// by all lower bits, so inside a digit's run of the block the full keys never decrease: a key starts where it differs from
+// its predecessor in the run (or opens the run).
+template <bool LAST>
 __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_t* __restrict__ keys_in,
                                                                    const uint32_t* __restrict__ vals_in,
                                                                    uint32_t* __restrict__ keys_out,
                                                                    uint32_t* __restrict__ vals_out, int64_t n,
                                                                    int shift, const uint32_t* __restrict__ ghist_scanned,
-                                                                   int nblk)
+                                                                   int nblk, uint32_t* __restrict__ tile_first)
 {
     __shared__ uint32_t s_cnt[4 * 256]; // per-wave running digit counts, then per-wave exclusive bases
     __shared__ uint32_t s_gbase[256];   // global start of (digit, this block)
@@ -240,9 +251,64 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
         const uint32_t k = s_key[p];
         const uint32_t digit = (k >> shift) & 255u;
         const uint32_t dest = s_gbase[digit] + (p - s_boff[digit]);
-        keys_out[dest] = k;
         vals_out[dest] = s_val[p];
+        if (LAST) {
+            if (p == s_boff[digit] || s_key[p - 1] != k) atomicMin(&tile_first[k], dest);
+        } else {
+            keys_out[dest] = k;
+        }
     }
+}
+
+// tile_off[t] = first position whose key is >= t = min over k >= t of tile_first[k] (0xFFFFFFFF: no pair of that key),
+// tile_off[num_keys] = total.  Two small launches over chunks of 1024 keys: the chunks' minima, then every chunk's suffix
+// minimum seeded with the minimum of the chunks behind it.
+constexpr int kFirstChunk = 1024;
+
+__device__ __forceinline__ uint32_t block_min_1024(uint32_t v, uint32_t* s16)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_down((int)v, d, 64));
+    if ((threadIdx.x & 63) == 0) s16[threadIdx.x >> 6] = v;
+    __syncthreads();
+    uint32_t m = s16[0];
+#pragma unroll
+    for (int k = 1; k < kFirstChunk / 64; k++) m = min(m, s16[k]);
+    __syncthreads();
+    return m;
+}
+
+__global__ __launch_bounds__(kFirstChunk) void tile_first_chunk_min_kernel(const uint32_t* __restrict__ tile_first, int num_keys,
+                                                                           uint32_t* __restrict__ chunk_min)
+{
+    __shared__ uint32_t s16[kFirstChunk / 64];
+    const int k = blockIdx.x * kFirstChunk + threadIdx.x;
+    const uint32_t m = block_min_1024(k < num_keys ? tile_first[k] : 0xFFFFFFFFu, s16);
+    if (threadIdx.x == 0) chunk_min[blockIdx.x] = m;
+}
+
+__global__ __launch_bounds__(kFirstChunk) void tile_offsets_from_first_kernel(const uint32_t* __restrict__ tile_first, int num_keys,
+                                                                              const uint32_t* __restrict__ chunk_min, int num_chunks,
+                                                                              uint32_t total, uint32_t* __restrict__ tile_off)
+{
+    __shared__ uint32_t s16[kFirstChunk / 64];
+    __shared__ uint32_t s_v[kFirstChunk];
+    const int t = threadIdx.x, k = blockIdx.x * kFirstChunk + t;
+    // everything behind this chunk
+    uint32_t behind = total;
+    for (int c = (int)blockIdx.x + 1 + t; c < num_chunks; c += kFirstChunk) behind = min(behind, chunk_min[c]);
+    behind = block_min_1024(behind, s16);
+    // suffix minimum inside the chunk (Hillis-Steele)
+    s_v[t] = k < num_keys ? tile_first[k] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (int d = 1; d < kFirstChunk; d <<= 1) {
+        const uint32_t other = (t + d < kFirstChunk) ? s_v[t + d] : 0xFFFFFFFFu;
+        __syncthreads();
+        s_v[t] = min(s_v[t], other);
+        __syncthreads();
+    }
+    if (k < num_keys) tile_off[k] = min(s_v[t], behind);
+    if (k == num_keys) tile_off[num_keys] = total; // (num_keys a multiple of the chunk: written by thread 0 of an extra block)
 }
 
 static inline int64_t sort_blocks(int64_t n) { return (n + kSortItemsPerBlock - 1) / kSortItemsPerBlock; }
@@ -254,7 +320,7 @@ size_t sort_temp_words(int64_t n)
 }
 
 hipError_t sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, int64_t n,
-                          int key_bits, uint32_t* temp, uint32_t** keys_out, uint32_t** vals_out,
+                          int key_bits, uint32_t* temp, uint32_t** keys_out, uint32_t** vals_out, uint32_t* tile_first,
                           hipStream_t stream)
 {
     uint32_t *kin = keys_a, *vin = vals_a, *kout = keys_b, *vout = vals_b;
@@ -267,15 +333,31 @@ hipError_t sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, 
                                ghist, (int)nblk);
             hipError_t e = exclusive_scan_u32(ghist, ghist, 256 * nblk, scan_temp, nullptr, stream);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nblk), dim3(kSortBlock), 0, stream, kin, vin,
-                               kout, vout, n, shift, ghist, (int)nblk);
+            if (tile_first && shift + 8 >= key_bits)
+                hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3((unsigned)nblk), dim3(kSortBlock), 0, stream, kin, vin,
+                                   kout, vout, n, shift, ghist, (int)nblk, tile_first);
+            else
+                hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3((unsigned)nblk), dim3(kSortBlock), 0, stream, kin, vin,
+                                   kout, vout, n, shift, ghist, (int)nblk, tile_first);
             uint32_t* t;
             t = kin; kin = kout; kout = t;
             t = vin; vin = vout; vout = t;
         }
     }
-    *keys_out = kin;
+    *keys_out = kin; // (not written by the last pass when tile_first was asked for)
     *vals_out = vin;
+    return hipGetLastError();
+}
+
+size_t tile_first_temp_words(int num_keys) { return (size_t)(num_keys / kFirstChunk + 2); }
+
+hipError_t launch_tile_offsets_from_first(const uint32_t* tile_first, int num_keys, uint32_t total, uint32_t* temp,
+                                          uint32_t* tile_off, hipStream_t stream)
+{
+    const int chunks = num_keys / kFirstChunk + 1; // covers key num_keys itself (the end marker) too
+    hipLaunchKernelGGL(tile_first_chunk_min_kernel, dim3(chunks), dim3(kFirstChunk), 0, stream, tile_first, num_keys, temp);
+    hipLaunchKernelGGL(tile_offsets_from_first_kernel, dim3(chunks), dim3(kFirstChunk), 0, stream, tile_first, num_keys, temp,
+                       chunks, total, tile_off);
     return hipGetLastError();
 }
 

@@ -20,11 +20,16 @@ WORKLOADS = [("4096^2/1M", 4096, 4096, 1_000_000, 200, None), ("2048^2/250k", 20
              ("535x426/50k", 535, 426, 50_000, 2000, None), ("268x213/1024 (as shipped)", 268, 213, 1024, 5000, None)]
 
 
+MODE = {}
+
+
 def run(path, W, H, n, iters, rows):
     S2D._lib = None
     L = S2D.load_library(path)
     S2D._lib = L
-    kw = {} if rows is None else {"row_begin": rows[0], "row_end": rows[1]}
+    kw = dict(MODE)
+    if rows is not None:
+        kw.update(row_begin=rows[0], row_end=rows[1])
     with S2D.Trainer(W, H, n, **kw) as t:
         t.set_target_synthetic()
         t.init()
@@ -43,7 +48,13 @@ def main():
     ap.add_argument("libs", nargs="+")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--only", type=int, default=-1, help="index into the workload list")
+    ap.add_argument("--deterministic", action="store_true", help="contexts with S2D_CFG_DETERMINISTIC")
+    ap.add_argument("--fp16-images", action="store_true")
     args = ap.parse_args()
+    if args.deterministic:
+        MODE["deterministic"] = True
+    if args.fp16_images:
+        MODE["fp16_images"] = True
     libs = [os.path.abspath(p) for p in args.libs]
     for k, (name, W, H, n, iters, rows) in enumerate(WORKLOADS):
         if args.only >= 0 and k != args.only:
