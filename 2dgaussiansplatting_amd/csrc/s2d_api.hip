@@ -37,6 +37,7 @@ struct s2d_ctx {
     // parameters / optimiser state / gradients (AoS, the reference's layouts)
     float* d_splats = nullptr;   // n * 9
     float* d_adams = nullptr;    // n * 18
+    uint8_t* d_dormant = nullptr; // n: 1 = all of the splat's Adam moments are zero (adam_kernel keeps it; cleared with every outside write)
     float* d_grads_own = nullptr;
     float* d_grads = nullptr;    // buffer in use (own or bound)
     // projection + binning
@@ -381,7 +382,7 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
                            c->lr,
                            ((flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0) | ((c->cfg.flags & S2D_CFG_ADAM_FP32) ? 2 : 0),
                            c->iterations, c->d_status,
-                           fuse ? c->d_proj : nullptr, c->d_rects, c->check_seq, c->h_rebin_stamp,
+                           fuse ? c->d_proj : nullptr, c->d_rects, c->check_seq, c->h_rebin_stamp, c->d_dormant,
                            c->sqerr_deferred ? SqerrJob{c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + c->last_sqerr_slot,
                                                         c->d_tile_sqerr + c->g.num_tiles}
                                              : SqerrJob{nullptr, 0, nullptr, nullptr},
@@ -393,6 +394,14 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
     c->since_rebin++;
     c->have_forward = false;
     c->have_backward = false;
+    return S2D_OK;
+}
+
+// Splats or Adam moments are about to be written from outside the Adam kernel: nothing is known to be dormant any more
+// (the next step of every splat is a full one, which also applies the constraints to whatever was loaded).
+int clear_dormant(s2d_ctx* c)
+{
+    if (c->n > 0) S2D_HIP(c, hipMemsetAsync(c->d_dormant, 0, (size_t)c->n, c->stream));
     return S2D_OK;
 }
 
@@ -492,6 +501,7 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     const size_t px = (size_t)g.W * (size_t)(g.row_end - g.row_begin); // pixels of the slab: all this context stores
     S2D_HIP(c, dev_alloc(&c->d_splats, n * 9));
     S2D_HIP(c, dev_alloc(&c->d_adams, n * 18));
+    S2D_HIP(c, dev_alloc(&c->d_dormant, n));
     S2D_HIP(c, dev_alloc(&c->d_grads_own, n * 9));
     c->d_grads = c->d_grads_own;
     S2D_HIP(c, dev_alloc(&c->d_proj, n));
@@ -526,6 +536,7 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
 
     S2D_HIP(c, hipMemsetAsync(c->d_splats, 0, n * 9 * sizeof(float), c->stream));
     S2D_HIP(c, hipMemsetAsync(c->d_adams, 0, n * 18 * sizeof(float), c->stream));
+    S2D_HIP(c, hipMemsetAsync(c->d_dormant, 0, n, c->stream));
     S2D_HIP(c, hipMemsetAsync(c->d_grads_own, 0, n * 9 * sizeof(float), c->stream));
     S2D_HIP(c, hipMemsetAsync(c->d_image0, 0, px * c->pixel_bytes, c->stream));
     S2D_HIP(c, hipMemsetAsync(c->d_ref, 0, px * c->pixel_bytes, c->stream));
@@ -546,7 +557,7 @@ void s2d_destroy(s2d_ctx* c)
     if (!c) return;
     if (hipSetDevice(c->device) == hipSuccess) {
         if (c->stream) (void)hipStreamSynchronize(c->stream);
-        void* ptrs[] = {c->d_splats, c->d_adams, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
+        void* ptrs[] = {c->d_splats, c->d_adams, c->d_dormant, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
                         c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_det_touched, c->d_tile_off, c->d_tile_first, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work, c->d_sqerr_trace,
                         c->d_status, c->d_counters};
@@ -605,6 +616,7 @@ int s2d_init_splats(s2d_ctx* c)
     if (int rc = use_device(c)) return rc;
     if (int rc = flush_sqerr(c)) return rc;
     S2D_HIP(c, launch_init_splats(c->d_splats, c->d_adams, c->n, c->g.W, c->g.H, c->stream));
+    if (int rc = clear_dormant(c)) return rc;
     if (c->n > 0) S2D_HIP(c, hipMemsetAsync(c->d_grads, 0, (size_t)c->n * 9 * sizeof(float), c->stream));
     if (int rc = reset_status(c)) return rc;
     c->beta1t = c->good_beta1t = 1.0f; // main.cpp:283-284
@@ -621,6 +633,7 @@ int s2d_set_splats(s2d_ctx* c, const s2d_splat* splats)
     if (!c || (!splats && c->n)) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
     S2D_HIP(c, hipMemcpyAsync(c->d_splats, splats, (size_t)c->n * sizeof(s2d_splat), hipMemcpyHostToDevice, c->stream));
+    if (int rc = clear_dormant(c)) return rc;
     if (int rc = reset_status(c)) return rc;
     S2D_HIP(c, hipStreamSynchronize(c->stream));
     c->lists_valid = false;
@@ -644,6 +657,7 @@ int s2d_set_adam(s2d_ctx* c, const s2d_splat_adam* adams, float beta1t, float be
     if (int rc = use_device(c)) return rc;
     if (int rc = flush_sqerr(c)) return rc; // (its ring slot is named by the iteration count about to change)
     S2D_HIP(c, hipMemcpyAsync(c->d_adams, adams, (size_t)c->n * sizeof(s2d_splat_adam), hipMemcpyHostToDevice, c->stream));
+    if (int rc = clear_dormant(c)) return rc;
     S2D_HIP(c, hipStreamSynchronize(c->stream));
     c->beta1t = c->good_beta1t = beta1t;
     c->beta2t = c->good_beta2t = beta2t;
@@ -882,6 +896,8 @@ int s2d_rows_scatter(s2d_ctx* c, int32_t what, const int32_t* ids_device, int32_
     if (int rc = rows_base(c, what, &base, &w)) return rc;
     if (int rc = use_device(c)) return rc;
     S2D_HIP(c, launch_rows_scatter(base, w, ids_device, count, c->n, in_device, c->stream));
+    if (what == S2D_ROWS_SPLATS || what == S2D_ROWS_ADAM)
+        if (int rc = clear_dormant(c)) return rc;
     if (what == S2D_ROWS_SPLATS) { // parameters changed behind the projection
         c->proj_fresh = false;
         c->have_forward = false;

@@ -296,10 +296,14 @@ hipError_t launch_sqerr_finalize(const double* tile_sqerr, int num_tiles, double
 hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, hipStream_t stream);
 // proj != nullptr: also project the UPDATED splat for the next iteration and check it against rects[]
 // (what project_kernel mode 1 would do), raising status->rebin_needed.
+// dormant (n bytes, or nullptr): dormant[i] = 1 while every Adam moment of splat i is zero -- maintained by the kernel,
+// cleared by whoever else writes splats or moments; a block whose splats are all dormant and received zero gradients skips
+// the step, which would leave them bit for bit as they are.
 hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t* held_ids, const uint32_t* held_count, int n,
                        Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
-                       const TileRect* rects, int check_stamp, int* host_stamp, SqerrJob sq, hipStream_t stream);
+                       const TileRect* rects, int check_stamp, int* host_stamp, uint8_t* dormant, SqerrJob sq,
+                       hipStream_t stream);
 // image_ref: rows [row_begin, row_end) of the W x H target
 hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, int row_begin, int row_end, hipStream_t stream);
 // RGBA32F <-> 4 x fp16 (round to nearest even) for images that cross the boundary as floats

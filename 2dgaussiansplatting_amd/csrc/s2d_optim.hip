@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
                                                    float beta1t, float beta2t, float lr, int mode, int iteration,
                                                    DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
                                                    const TileRect* __restrict__ rects, int check_stamp,
-                                                   int* __restrict__ host_stamp, SqerrJob sq)
+                                                   int* __restrict__ host_stamp, uint8_t* __restrict__ dormant, SqerrJob sq)
 {
     __shared__ __attribute__((aligned(16))) float buf[256 * 18];
     __shared__ uint32_t s_idbuf[256];
@@ -158,7 +158,18 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 9; k++) gr[k] = mine ? buf[t * 9 + k] : 0.0f;
-    __syncthreads();
+    // A splat no live pixel sees receives a zero gradient; if its moments are zero as well (dormant[i]: they were after its
+    // last full update, and nothing but this kernel has touched it since) the whole of main.cpp:721-750 leaves it exactly as
+    // it is: m = v = 0, the step 0 / (0 + 1e-15), the clamps already applied.  Splats are blended in index order, so the
+    // hidden ones sit together at the high indices (about 60 % of 10^6 on a 4096^2 image): a block made of them has nothing
+    // to read, write, project or check beyond the gradients it has just looked at.
+    bool live = false;
+    if (mine) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) live = live || (gr[k] != 0.0f);
+        if (!live) live = dormant == nullptr || dormant[i] == 0;
+    }
+    if (!__syncthreads_or(live)) return;
     for (int q = t; q < 256 * 9 / 4; q += 256) reinterpret_cast<float4*>(buf)[q] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
     lds_drain<9>(grads, buf, s_ids, base, cnt);
@@ -176,6 +187,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
     for (int k = 0; k < 18; k++) mv[k] = mine ? buf[t * 18 + k] : 0.0f;
     if (mine) {
         adam_update_one(v, mv, gr, g.W, g.H, beta1t, beta2t, lr, mode, iteration, status);
+        if (dormant) { // all eighteen moments zero (+0 or -0): the next zero gradient changes nothing
+            uint32_t any = 0u;
+#pragma unroll
+            for (int k = 0; k < 18; k++) any |= f32_bits(mv[k]) << 1;
+            dormant[i] = any == 0u ? 1 : 0;
+        }
         // moments out (each thread rewrites only its own record of the block's copy; the opacity slot goes back
         // unchanged when the checkbox is off)
 #pragma unroll
@@ -256,11 +273,12 @@ hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, 
 hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t* held_ids, const uint32_t* held_count,
                        int n, Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
-                       const TileRect* rects, int check_stamp, int* host_stamp, SqerrJob sq, hipStream_t stream)
+                       const TileRect* rects, int check_stamp, int* host_stamp, uint8_t* dormant, SqerrJob sq,
+                       hipStream_t stream)
 {
     if (n <= 0) return hipSuccess; // (callers queue the standalone squared-error reduction themselves when n == 0)
     hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, held_ids, held_count, n, g,
-                       beta1t, beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, sq);
+                       beta1t, beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, dormant, sq);
     return hipGetLastError();
 }
 

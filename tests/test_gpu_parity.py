@@ -1224,6 +1224,50 @@ def test_multi_device_handle_forward_after_new_splats_uses_fresh_hold_sets(world
         assert back.tobytes() == t.get_image().tobytes()
 
 
+def test_dormant_splats_wake_up_when_their_state_is_written_from_outside():
+    """The Adam kernel skips blocks of splats whose moments are all zero and whose gradients came back zero (hidden splats:
+    the step would leave them bit for bit as they are) and remembers them as dormant.  Every outside write of parameters or
+    moments must cancel that: a context that has trained (and marked its hidden splats) is handed new moments / new
+    parameters and must then step exactly like a fresh context handed the same state (deterministic gradients: bitwise)."""
+    W, H, n = 512, 512, 60000          # dense enough that the high indices are hidden: whole blocks go dormant
+    with S2D.Trainer(W, H, n, deterministic=True) as a:
+        a.set_target_synthetic()
+        a.init()
+        a.step(6)
+        sp = a.get_splats()
+        ad, b1, b2, it = a.get_adam()
+        hidden = np.flatnonzero(~ad["mv"].reshape(n, -1).any(axis=1))
+        assert hidden.size > 2000 and (np.diff(hidden) == 1).sum() > 1000   # zero moments, in long runs of indices
+        assert np.array_equal(sp[hidden], a_init_splats(W, H, n)[hidden])        # ... and they never moved
+        # 1. new moments for some hidden splats (as a checkpoint load would bring): they must move now
+        ad2 = ad.copy()
+        ad2["mv"][hidden[::7], 0, 0] = 0.25     # m of pos.x
+        ad2["mv"][hidden[::7], 0, 1] = 0.01     # v of pos.x
+        a.set_adam(ad2, b1, b2, it)
+        a.step(1)
+        got = a.get_splats()
+        with S2D.Trainer(W, H, n, deterministic=True) as b:
+            b.set_target_synthetic()
+            b.set_splats(sp)
+            b.set_adam(ad2, b1, b2, it)
+            b.step(1)
+            want = b.get_splats()
+        assert got.tobytes() == want.tobytes()
+        assert np.all(got["pos"][hidden[::7], 0] != sp["pos"][hidden[::7], 0])
+        # 2. parameters outside the constraints for hidden splats (set_splats): the next step clamps them (main.cpp:741-749)
+        sp3 = got.copy()
+        sp3["sx"][hidden[3::11]] = 0.25
+        a.set_splats(sp3)
+        a.step(1)
+        assert np.all(a.get_splats()["sx"][hidden[3::11]] == 1.0)
+
+
+def a_init_splats(W, H, n):
+    with S2D.Trainer(W, H, n) as t:
+        t.init()
+        return t.get_splats()
+
+
 def test_backward_refuses_a_framebuffer_the_fused_launch_did_not_store():
     """s2d_forward_backward with S2D_FB_SKIP_IMAGE leaves an OLDER frame in image0: a following s2d_backward, which reads
     image0, must refuse (S2D_E_STATE) instead of differentiating against that frame; with the image stored it runs."""
