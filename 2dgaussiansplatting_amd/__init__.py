@@ -30,6 +30,7 @@ S2D_CFG_FP16_IMAGES = 0x2
 S2D_CFG_DETERMINISTIC = 0x4
 S2D_CFG_EXACT_EXP = 0x8
 S2D_CFG_ADAM_FP32 = 0x10
+S2D_CFG_GENERIC_BINNING = 0x20
 S2D_BWD_SKIP_OPACITY_GRAD = 0x1
 S2D_FB_SKIP_IMAGE = 0x2
 STATUS_NAMES = {0: "S2D_OK", 1: "S2D_E_INVALID", 2: "S2D_E_HIP", 3: "S2D_E_NONFINITE", 4: "S2D_E_NOMEM",
@@ -233,7 +234,7 @@ class Trainer:
 
     def __init__(self, width, height, n_splats, device=0, row_begin=0, row_end=0, training_rate=0.0,
                  rebin_interval=0, rebin_margin=0.0, count_pairs=False, fp16_images=False, deterministic=False, exact_exp=False,
-                 adam_fp32=False, stream=None):
+                 adam_fp32=False, generic_binning=False, stream=None):
         self.L = load_library()
         self.W, self.H, self.n = int(width), int(height), int(n_splats)
         cfg = _Config()
@@ -244,7 +245,7 @@ class Trainer:
         cfg.training_rate = float(training_rate)
         cfg.flags = ((S2D_CFG_COUNT_PAIRS if count_pairs else 0) | (S2D_CFG_FP16_IMAGES if fp16_images else 0) |
                      (S2D_CFG_DETERMINISTIC if deterministic else 0) | (S2D_CFG_EXACT_EXP if exact_exp else 0) |
-                     (S2D_CFG_ADAM_FP32 if adam_fp32 else 0))
+                     (S2D_CFG_ADAM_FP32 if adam_fp32 else 0) | (S2D_CFG_GENERIC_BINNING if generic_binning else 0))
         cfg.rebin_interval = int(rebin_interval)
         cfg.rebin_margin = float(rebin_margin)
         cfg.stream = stream

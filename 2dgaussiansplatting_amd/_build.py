@@ -16,8 +16,8 @@ LIB_PATH = os.path.join(LIB_DIR, "libsplat2d_hip.so")
 HOST_DIR = os.path.join(PKG_DIR, "host")
 TRAIN_BIN = os.path.join(LIB_DIR, "splat2d_train")
 
-HIP_SOURCES = ["s2d_api.hip", "s2d_scan_sort.hip", "s2d_binning.hip", "s2d_raster.hip", "s2d_optim.hip", "s2d_halo.hip",
-               "s2d_multi.hip"]
+HIP_SOURCES = ["s2d_api.hip", "s2d_scan_sort.hip", "s2d_binning.hip", "s2d_tilelists.hip", "s2d_raster.hip", "s2d_optim.hip",
+               "s2d_halo.hip", "s2d_multi.hip"]
 HIP_HEADERS = ["s2d_device.h", "s2d_math.h"]
 
 # -ffp-contract=off: the kernels keep the reference's evaluation order (no FMA contraction) wherever a

@@ -59,6 +59,14 @@ struct s2d_ctx {
     uint64_t pair_capacity = 0;
     uint32_t* d_tile_off = nullptr;
     uint32_t* d_tile_first = nullptr; // per tile id (padded to a power of two): position of its first pair (last radix pass)
+    // tile lists in two levels (s2d_tilelists.hip): (splat, tile row) entries sorted by row, then per-row counting sort by column
+    bool two_level = false;            // tiles_x <= kTlMaxColumns and not S2D_CFG_GENERIC_BINNING
+    uint32_t* d_row_counts = nullptr;  // per splat: tile rows its rectangle covers
+    uint32_t* d_row_offsets = nullptr; // ... scanned
+    uint32_t* d_row_off = nullptr;     // [tiles_y + 1]: where each tile row's entries begin
+    uint32_t* d_chunk_base = nullptr;  // [tiles_y + 1]
+    uint32_t* d_tl_hist = nullptr;     // per (row, column, chunk) counts + scan workspace
+    size_t tl_hist_capacity = 0;       // words
     uint32_t* d_list = nullptr; // == one of d_vals after the sort
     uint64_t pairs = 0;
     uint64_t rebins = 0;
@@ -182,19 +190,45 @@ int ensure_pair_capacity(s2d_ctx* c, uint64_t need)
     return S2D_OK;
 }
 
+// The workspace of the two-level builder grows with the number of (splat, tile row) entries.
+int ensure_tl_hist(s2d_ctx* c, uint64_t entries)
+{
+    const size_t need = tl_workspace_words(entries, c->g.tiles_x, c->g.tiles_y);
+    if (need <= c->tl_hist_capacity) return S2D_OK;
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    if (c->d_tl_hist) S2D_HIP(c, hipFree(c->d_tl_hist));
+    c->d_tl_hist = nullptr;
+    c->tl_hist_capacity = 0;
+    const size_t cap = need + need / 4 + 4096;
+    S2D_HIP(c, dev_alloc(&c->d_tl_hist, cap));
+    c->tl_hist_capacity = cap;
+    return S2D_OK;
+}
+
 // (Re)build the per-tile lists from the current parameters.  The projection has already been queued with mode 0.
+// Two builders with the same result (every tile's list ascending in splat index): the two-level one of s2d_tilelists.hip
+// (images of up to kTlMaxColumns tile columns), and the generic one -- all (tile, splat) pairs emitted in splat order and
+// radix-sorted by tile -- for wider images and on request (S2D_CFG_GENERIC_BINNING).
 int rebuild_lists(s2d_ctx* c)
 {
     const int n = c->n;
-    // the scan's last kernel stores the pair count into host-mapped memory itself (no copy engine between two kernels)
+    // the scans' last kernels store their totals into host-mapped memory themselves (no copy engine between two kernels)
     S2D_HIP(c, exclusive_scan_u32(c->d_counts, c->d_offsets, n, c->d_scan_temp, c->d_total, c->stream, c->h_total));
+    if (c->two_level)
+        S2D_HIP(c, exclusive_scan_u32(c->d_row_counts, c->d_row_offsets, n, c->d_scan_temp, c->d_total + 1, c->stream, c->h_total + 1));
     S2D_HIP(c, hipEventRecord(c->ev_total, c->stream));
-    // The pair emission needs the offsets, not the total (it never writes past the buffers' capacity): queue it behind the
-    // scan and wait for the SCAN only, so the host reads the total and queues the sort while the emission runs instead of
-    // the device idling through the host's round trip (~30 us per rebuild).  Only when the pairs outgrow the buffers
+    // The emission needs the offsets, not the totals (it never writes past the buffers' capacity): queue it behind the
+    // scans and wait for the SCANS only, so the host reads the totals and queues the rest while the emission runs instead
+    // of the device idling through the host's round trip (~30 us per rebuild).  Only when the pairs outgrow the buffers
     // (rare: they are sized with a quarter to spare) is the emission queued again.
-    S2D_HIP(c, launch_emit_pairs(c->d_rects, c->d_offsets, c->d_counts, n, c->g, c->d_keys[0], c->d_vals[0],
-                                 (uint32_t)c->pair_capacity, c->stream));
+    auto emit = [&]() -> hipError_t {
+        if (c->two_level) // (there are never more entries than pairs: the pair buffers hold them)
+            return launch_emit_row_entries(c->d_rects, c->d_row_offsets, c->d_row_counts, n, c->d_keys[0], c->d_vals[0],
+                                           (uint32_t)c->pair_capacity, c->stream);
+        return launch_emit_pairs(c->d_rects, c->d_offsets, c->d_counts, n, c->g, c->d_keys[0], c->d_vals[0], (uint32_t)c->pair_capacity,
+                                 c->stream);
+    };
+    S2D_HIP(c, emit());
     S2D_HIP(c, hipEventSynchronize(c->ev_total));
     const uint64_t total = *(volatile uint32_t*)c->h_total; // saturates at 0xFFFFFFFF instead of wrapping (scan_top_kernel)
     if (total >= 0xFFFF0000ull)
@@ -202,24 +236,46 @@ int rebuild_lists(s2d_ctx* c)
     if (total > c->pair_capacity) {
         int rc = ensure_pair_capacity(c, total);
         if (rc != S2D_OK) return rc;
-        S2D_HIP(c, launch_emit_pairs(c->d_rects, c->d_offsets, c->d_counts, n, c->g, c->d_keys[0], c->d_vals[0],
-                                     (uint32_t)c->pair_capacity, c->stream));
+        S2D_HIP(c, emit());
     }
     uint32_t *k_out = nullptr, *v_out = nullptr;
-    const int key_bits = key_bits_for(c->g.num_tiles);
-    if (key_bits > 0) {
-        // the last radix pass records where each tile's pairs begin instead of writing the sorted keys out
-        S2D_HIP(c, hipMemsetAsync(c->d_tile_first, 0xFF, ((size_t)1 << key_bits) * sizeof(uint32_t), c->stream));
-        S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)total, key_bits,
-                                  c->d_sort_temp, &k_out, &v_out, c->d_tile_first, c->stream));
-        S2D_HIP(c, launch_tile_offsets_from_first(c->d_tile_first, c->g.num_tiles, (uint32_t)total,
-                                                  c->d_tile_first + ((size_t)1 << key_bits), c->d_tile_off, c->stream));
-    } else { // a single tile: nothing to sort
-        S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)total, key_bits,
-                                  c->d_sort_temp, &k_out, &v_out, nullptr, c->stream));
-        S2D_HIP(c, launch_tile_offsets(k_out, (uint32_t)total, c->g.num_tiles, c->d_tile_off, c->stream));
+    if (c->two_level) {
+        const uint64_t entries = *(volatile uint32_t*)(c->h_total + 1);
+        if (int rc = ensure_tl_hist(c, entries)) return rc;
+        const int row_bits = key_bits_for(c->g.tiles_y);
+        if (row_bits > 0) { // level 1: the entries by tile row, and where every row begins
+            // (sorted keys written out and compared: with only tiles_y distinct keys the last pass's atomicMin per (block,
+            // key) would pile thousands of atomics on each of a few hundred words)
+            S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)entries, row_bits,
+                                      c->d_sort_temp, &k_out, &v_out, nullptr, c->stream));
+            S2D_HIP(c, launch_tile_offsets(k_out, (uint32_t)entries, c->g.tiles_y, c->d_row_off, c->stream));
+        } else { // one tile row: the emission order is the row's order
+            const uint32_t two[2] = {0u, (uint32_t)entries};
+            S2D_HIP(c, hipMemcpyAsync(c->d_row_off, two, sizeof(two), hipMemcpyHostToDevice, c->stream));
+            S2D_HIP(c, hipStreamSynchronize(c->stream)); // (`two` lives on this stack frame)
+            v_out = c->d_vals[0];
+        }
+        // level 2: every row's entries by column, straight into the lists (the value buffer the sort finished with is free)
+        uint32_t* list = v_out == c->d_vals[0] ? c->d_vals[1] : c->d_vals[0];
+        S2D_HIP(c, launch_tile_lists_from_rows(v_out, entries, c->d_rects, c->d_row_off, c->g, c->d_chunk_base, c->d_tl_hist,
+                                               c->d_tile_off, list, c->stream));
+        c->d_list = list;
+    } else {
+        const int key_bits = key_bits_for(c->g.num_tiles);
+        if (key_bits > 0) {
+            // the last radix pass records where each tile's pairs begin instead of writing the sorted keys out
+            S2D_HIP(c, hipMemsetAsync(c->d_tile_first, 0xFF, ((size_t)1 << key_bits) * sizeof(uint32_t), c->stream));
+            S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)total, key_bits,
+                                      c->d_sort_temp, &k_out, &v_out, c->d_tile_first, c->stream));
+            S2D_HIP(c, launch_tile_offsets_from_first(c->d_tile_first, c->g.num_tiles, (uint32_t)total,
+                                                      c->d_tile_first + ((size_t)1 << key_bits), c->d_tile_off, c->stream));
+        } else { // a single tile: nothing to sort
+            S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)total, key_bits,
+                                      c->d_sort_temp, &k_out, &v_out, nullptr, c->stream));
+            S2D_HIP(c, launch_tile_offsets(k_out, (uint32_t)total, c->g.num_tiles, c->d_tile_off, c->stream));
+        }
+        c->d_list = v_out;
     }
-    c->d_list = v_out;
     c->pairs = total;
     c->rebins++;
     c->lists_valid = true;
@@ -279,7 +335,7 @@ int queue_raster(s2d_ctx* c, const RasterJob& job)
     if (!scheduled) {
         if (!c->proj_fresh) { // parameters changed without a fused projection: project + check now
             c->check_seq++;
-            S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, 0.0f, 1, c->d_proj, c->d_rects, c->d_counts, c->d_status,
+            S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, 0.0f, 1, c->d_proj, c->d_rects, c->d_counts, nullptr, c->d_status,
                                       c->check_seq, c->h_rebin_stamp, c->stream));
             S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
             c->proj_fresh = true;
@@ -289,8 +345,8 @@ int queue_raster(s2d_ctx* c, const RasterJob& job)
         rebuild = *(volatile int*)c->h_rebin_stamp == c->check_seq;
     }
     if (rebuild) {
-        S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, c->margin, 0, c->d_proj, c->d_rects, c->d_counts, c->d_status,
-                                  0, nullptr, c->stream));
+        S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, c->margin, 0, c->d_proj, c->d_rects, c->d_counts,
+                                  c->two_level ? c->d_row_counts : nullptr, c->d_status, 0, nullptr, c->stream));
         if (int rc = rebuild_lists(c)) return rc;
         c->proj_fresh = true;
         c->check_seq++; // the new lists cover the current parameters: a stamp that asked for them matches nothing now
@@ -509,9 +565,16 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, dev_alloc(&c->d_counts, n));
     S2D_HIP(c, dev_alloc(&c->d_offsets, n));
     S2D_HIP(c, dev_alloc(&c->d_scan_temp, scan_temp_words((int64_t)n)));
-    S2D_HIP(c, dev_alloc(&c->d_total, 4));
+    S2D_HIP(c, dev_alloc(&c->d_total, 4)); // [0] pairs, [1] (splat, tile row) entries
     S2D_HIP(c, dev_alloc(&c->d_tile_off, (size_t)g.num_tiles + 1));
     S2D_HIP(c, dev_alloc(&c->d_tile_first, ((size_t)1 << key_bits_for(g.num_tiles)) + tile_first_temp_words(g.num_tiles))); // + chunk minima
+    c->two_level = g.tiles_x <= kTlMaxColumns && !(cfg->flags & S2D_CFG_GENERIC_BINNING);
+    if (c->two_level) {
+        S2D_HIP(c, dev_alloc(&c->d_row_counts, n));
+        S2D_HIP(c, dev_alloc(&c->d_row_offsets, n));
+        S2D_HIP(c, dev_alloc(&c->d_row_off, (size_t)g.tiles_y + 1));
+        S2D_HIP(c, dev_alloc(&c->d_chunk_base, (size_t)g.tiles_y + 1));
+    }
     c->deterministic = (cfg->flags & S2D_CFG_DETERMINISTIC) != 0;
     if (c->deterministic) {
         S2D_HIP(c, dev_alloc(&c->d_det_touched, n));
@@ -559,7 +622,8 @@ void s2d_destroy(s2d_ctx* c)
         if (c->stream) (void)hipStreamSynchronize(c->stream);
         void* ptrs[] = {c->d_splats, c->d_adams, c->d_dormant, c->d_grads_own, c->d_proj, c->d_rects, c->d_counts, c->d_offsets,
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
-                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_det_touched, c->d_tile_off, c->d_tile_first, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work, c->d_sqerr_trace,
+                        c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_det_touched, c->d_tile_off, c->d_tile_first, c->d_row_counts, c->d_row_offsets, c->d_row_off,
+                        c->d_chunk_base, c->d_tl_hist, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work, c->d_sqerr_trace,
                         c->d_status, c->d_counters};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);

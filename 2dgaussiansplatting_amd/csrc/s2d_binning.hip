@@ -13,6 +13,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
                                                       const uint8_t* __restrict__ held, int n, Geometry g,
                                                       float margin, int mode, ProjRec* __restrict__ proj,
                                                       TileRect* __restrict__ rects, uint32_t* __restrict__ counts,
+                                                      uint32_t* __restrict__ row_counts,
                                                       DeviceStatus* __restrict__ status, int check_stamp,
                                                       int* __restrict__ host_stamp)
 {
@@ -24,6 +25,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
             e.tx0 = 1; e.tx1 = 0; e.ty0 = 1; e.ty1 = 0;
             rects[i] = e;
             counts[i] = 0u;
+            if (row_counts) row_counts[i] = 0u;
         }
         return;
     }
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
         else { r.tx0 = 1; r.tx1 = 0; r.ty0 = 1; r.ty1 = 0; }
         rects[i] = r;
         counts[i] = cnt;
+        if (row_counts) row_counts[i] = cnt ? (uint32_t)(r.ty1 - r.ty0 + 1) : 0u; // tile rows it covers (s2d_tilelists.hip)
     } else {
         if (!rect_still_covers(p, g, rects[i])) raise_rebin(status, check_stamp, host_stamp);
     }
@@ -55,6 +58,8 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
 // binary search over the block's offsets (LDS) and the tile from the position inside that splat's rectangle (row-major,
 // the order the stable sort then keeps).  Consecutive lanes write consecutive words.  (One thread per splat writing its
 // ~20 pairs one after the other made every store instruction touch 64 different cache lines: 180 us at 20 M pairs.)
+// ROWS: one entry per (splat, tile row) instead of one per (splat, tile): key = the row, counts = rows per splat.
+template <bool ROWS>
 __global__ __launch_bounds__(256) void emit_kernel(const TileRect* __restrict__ rects,
                                                    const uint32_t* __restrict__ offsets,
                                                    const uint32_t* __restrict__ counts, int n, int tiles_x,
@@ -86,10 +91,14 @@ __global__ __launch_bounds__(256) void emit_kernel(const TileRect* __restrict__ 
         }
         const TileRect r = s_rect[lo];
         const uint32_t local = q - s_off[lo], w = (uint32_t)(r.tx1 - r.tx0 + 1);
-        const uint32_t ty = r.ty0 + local / w, tx = r.tx0 + local % w;
         const uint32_t o = base + q;
         if (o < capacity) {
-            keys[o] = ty * (uint32_t)tiles_x + tx;
+            if (ROWS) {
+                keys[o] = r.ty0 + local;
+            } else {
+                const uint32_t ty = r.ty0 + local / w, tx = r.tx0 + local % w;
+                keys[o] = ty * (uint32_t)tiles_x + tx;
+            }
             vals[o] = (uint32_t)(first + lo);
         }
     }
@@ -108,12 +117,12 @@ __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __res
 }
 
 hipError_t launch_project(const float* splats, const uint8_t* held, int n, Geometry g, float margin, int mode, ProjRec* proj,
-                          TileRect* rects, uint32_t* counts, DeviceStatus* status, int check_stamp, int* host_stamp,
-                          hipStream_t stream)
+                          TileRect* rects, uint32_t* counts, uint32_t* row_counts, DeviceStatus* status, int check_stamp,
+                          int* host_stamp, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(project_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, held, n, g, margin, mode, proj,
-                       rects, counts, status, check_stamp, host_stamp);
+                       rects, counts, row_counts, status, check_stamp, host_stamp);
     return hipGetLastError();
 }
 
@@ -121,7 +130,16 @@ hipError_t launch_emit_pairs(const TileRect* rects, const uint32_t* offsets, con
                              uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(emit_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, rects, offsets, counts, n, g.tiles_x, keys,
+    hipLaunchKernelGGL(emit_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, stream, rects, offsets, counts, n, g.tiles_x, keys,
+                       vals, capacity);
+    return hipGetLastError();
+}
+
+hipError_t launch_emit_row_entries(const TileRect* rects, const uint32_t* row_offsets, const uint32_t* row_counts, int n,
+                                   uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(emit_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, stream, rects, row_offsets, row_counts, n, 1, keys,
                        vals, capacity);
     return hipGetLastError();
 }

@@ -158,13 +158,26 @@ hipError_t launch_tile_offsets_from_first(const uint32_t* tile_first, int num_ke
 // binning (s2d_binning.hip)
 // Projects every splat; mode 0: also writes rects[] (inflated by `margin` pixels) and counts[];
 // mode 1: checks that the exact rectangle lies inside rects[] and raises status->rebin_needed otherwise.
+// (mode 0, row_counts != nullptr: also the number of tile rows each rectangle covers)
 hipError_t launch_project(const float* splats, const uint8_t* held, int n, Geometry g, float margin, int mode, ProjRec* proj,
-                          TileRect* rects, uint32_t* counts, DeviceStatus* status, int check_stamp, int* host_stamp,
-                          hipStream_t stream);
+                          TileRect* rects, uint32_t* counts, uint32_t* row_counts, DeviceStatus* status, int check_stamp,
+                          int* host_stamp, hipStream_t stream);
+// one (tile row, splat) entry per row of every splat's rectangle, in splat order, at the scanned row offsets
+hipError_t launch_emit_row_entries(const TileRect* rects, const uint32_t* row_offsets, const uint32_t* row_counts, int n,
+                                   uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream);
 hipError_t launch_emit_pairs(const TileRect* rects, const uint32_t* offsets, const uint32_t* counts, int n, Geometry g,
                              uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream);
 hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, int num_tiles,
                                uint32_t* tile_off, hipStream_t stream);
+
+// tile lists in two levels (s2d_tilelists.hip): from the (splat, tile row) entries sorted by row -- `entries` holds the splat
+// indices, row_off[0 .. tiles_y] where each row's entries begin -- to tile_off[0 .. tiles] and the lists themselves.
+// Images of up to kTlMaxColumns tile columns.  workspace: tl_workspace_words(...) words; chunk_base: tiles_y + 1 words.
+constexpr int kTlMaxColumns = 512;
+size_t tl_workspace_words(uint64_t entries, int tiles_x, int tiles_y);
+hipError_t launch_tile_lists_from_rows(const uint32_t* entries, uint64_t num_entries, const TileRect* rects, const uint32_t* row_off,
+                                       Geometry g, uint32_t* chunk_base, uint32_t* workspace, uint32_t* tile_off, uint32_t* list,
+                                       hipStream_t stream);
 
 // raster (s2d_raster.hip)
 // abort_stamp != 0: when status->rebin_needed equals it at kernel start the launch does nothing -- the lists it would

@@ -107,6 +107,10 @@ typedef enum s2d_status {
                                     * of the parameter + ~3 ulp of the update per step; 100-iteration MSE traces by 2e-5
                                     * (tests/test_oracle_kat.py). */
 
+#define S2D_CFG_GENERIC_BINNING 0x20u /* diagnostic: build the tile lists with the generic builder (all (tile, splat) pairs
+                                    * radix-sorted by tile) even where the two-level one applies (images of up to 512 tile
+                                    * columns, csrc/s2d_tilelists.hip).  Same lists either way; wider images always use it. */
+
 typedef struct s2d_config {
     uint32_t struct_size;   /* = sizeof(s2d_config) */
     int32_t width, height;  /* imageRef.width(), .height() (main.cpp:254) */

@@ -229,6 +229,62 @@ def test_tile_lists_sorted_and_complete():
             assert (tile, i) in member
 
 
+def _lists(W, H, n, splats, generic, **kw):
+    with S2D.Trainer(W, H, n, generic_binning=generic, **kw) as t:
+        t.set_target_synthetic()
+        t.set_splats(splats)
+        t.forward()
+        tx, ty, off, lst = t.tile_lists()
+        return tx, ty, off.copy(), lst.copy(), t.get_image()
+
+
+@pytest.mark.parametrize("case", ["init_2048", "wide_5000", "adversarial", "slab", "one_tile_row", "one_tile", "empty"])
+def test_two_level_tile_lists_equal_the_sorted_pairs(case):
+    """The two builders of the per-tile lists -- (splat, tile row) entries sorted by row, then a counting sort by column per
+    row (s2d_tilelists.hip), and all (tile, splat) pairs radix-sorted by tile (S2D_CFG_GENERIC_BINNING) -- give the same
+    offsets and the same lists, word for word: init() scenes, more than 256 tile columns, splats from one pixel to the whole
+    image (a chunk whose pairs do not fit the staging buffer), row slabs, a single tile row, a single tile, no splat on
+    the image.  (Every list ascending in splat index: test_tile_lists_sorted_and_complete.)"""
+    kw = {}
+    if case == "init_2048":
+        W, H, n = 2048, 2048, 250_000
+        with S2D.Trainer(W, H, n) as t:
+            t.init()
+            sp = t.get_splats()
+    elif case == "wide_5000":
+        W, H, n = 5000, 700, 60_000            # 313 tile columns: the 512-column / 512-entry instantiation
+        sp = random_splats(n, W, H, 11)
+    elif case == "adversarial":
+        W, H, n = 1500, 1100, 6000
+        sp = random_splats(n, W, H, 5)
+        rng = np.random.default_rng(5)
+        sp["sx"] = rng.choice([1.0, 2.0, 8.0, 60.0, 400.0, 1024.0], n)   # many image-covering rectangles in every chunk
+        sp["sy"] = rng.choice([1.0, 3.0, 9.0, 80.0, 1024.0], n)
+        sp["pos"][:200] = [-500.0, -500.0]                                   # no footprint at all
+    elif case == "slab":
+        W, H, n = 1024, 1024, 40_000
+        sp = random_splats(n, W, H, 3)
+        kw = dict(row_begin=320, row_end=592)
+    elif case == "one_tile_row":
+        W, H, n = 900, 16, 3000
+        sp = random_splats(n, W, H, 4)
+    elif case == "one_tile":
+        W, H, n = 13, 9, 500
+        sp = random_splats(n, W, H, 6)
+    else:
+        W, H, n = 300, 200, 64
+        sp = random_splats(n, W, H, 7)
+        sp["pos"][:] = [-4000.0, -4000.0]
+    a = _lists(W, H, n, sp, False, **kw)
+    b = _lists(W, H, n, sp, True, **kw)
+    assert a[0] == b[0] and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]), "tile offsets differ"
+    assert np.array_equal(a[3], b[3]), "tile lists differ"
+    assert a[4].tobytes() == b[4].tobytes()
+    if case != "empty":
+        assert len(a[3]) > 0
+
+
 # ---------------------------------------------------------------------------------------------
 # backward / Adam / MSE
 # ---------------------------------------------------------------------------------------------
