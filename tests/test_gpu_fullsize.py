@@ -171,7 +171,7 @@ STEP_REL = 1e-4   # |delta_gpu - delta_oracle| <= 1e-4 of lr per scalar, beyond 
 
 def _report(name, stats):
     """Measured maxima, printed (pytest -s) and appended to gpurun_out/parity_report.txt (DESIGN.md section 5 quotes them)."""
-    line = "[parity] %s: %s" % (name, " ".join("%s=%.3g" % kv for kv in sorted(stats.items())))
+    line = "[parity] %s: %s" % (name, " ".join("%s=%.6g" % kv for kv in sorted(stats.items())))
     print("\n" + line)
     try:
         d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
