@@ -412,10 +412,10 @@ def main():
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
                          "kernel_ms": float(bwd_ms.item()), "algorithmic_bytes_per_launch": bwd_bytes,
                          "kernel_ms_note": "mean over the launches that did work; rocprofv3's AverageNs for this kernel also counts "
-                                           "one void ~22 us launch per list rebuild (profiles/r02/README.md)"},
+                                           "one void ~20 us launch per list rebuild (profiles/r03/README.md)"},
         }
         if world == 1:
-            # The path has no dense contraction (no MFMA) and the raster kernels are VALU-issue-bound, so beside the
+            # The path has no dense contraction (no MFMA) and the raster kernels are nowhere near bandwidth-bound, so beside the
             # HBM roofline report the useful fp32 VALU rate: active (pixel, splat) pairs per pass, counted by the
             # kernels in one extra untimed iteration, x 30 flop (forward, main.cpp:523-533) + 110 flop (backward,
             # main.cpp:607-709) per pair, against the 157.3 TFLOP/s fp32 vector peak.
@@ -433,7 +433,9 @@ def main():
                               "visited_pairs_per_pass": cs["bwd_visited"], "staged_list_entries_per_pass": cs["bwd_staged"],
                               "lanes_per_executed_wave_entry": cs["bwd_active"] / max(cs["bwd_wave_execs"], 1),
                               "executed_wave_entries_per_pass": cs["bwd_wave_execs"],
-                              "note": "useful fp32 VALU flops only; kernels are VALU-issue-bound (DESIGN.md section 4)"}
+                              "note": "useful fp32 VALU flops only (no FMA contraction is allowed: one flop per instruction); the raster kernel sits "
+                                      "between vector issue, the LDS pipe and per-wave latency (DESIGN.md section 4, "
+                                      "profiles/r03/r03_bound_experiments.txt)"}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or host_cores()
             out["cpu_baseline"] = cpu_baseline(W, H, n, threads)

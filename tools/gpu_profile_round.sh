@@ -1,13 +1,13 @@
 #!/bin/bash
 # GPU-box tool: the rocprofv3 passes behind profiles/rNN (run through gpurun from the repo root):
-#   bash tools/gpu_profile_round.sh r02
+#   bash tools/gpu_profile_round.sh r03
 # 1. --kernel-trace --stats of the default bench command            -> <tag>_kernel_stats.csv
 # 2. --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes          -> <tag>_pmc_traffic.csv   (per-launch means)
 # 3. two SQ / GRBM counter passes                                    -> <tag>_pmc_sq.csv
 # and profiles/traffic.json for bench.py's roofline.traffic (tied to the kernel sources by their digest).
 # rocprofv3 is given `python3 bench.py ...` directly (no shell / env hop); counters are collected with --kernel-trace only.
 set -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/profile_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
