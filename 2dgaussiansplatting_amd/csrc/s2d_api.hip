@@ -248,16 +248,17 @@ int rebuild_lists(s2d_ctx* c)
             // key) would pile thousands of atomics on each of a few hundred words)
             S2D_HIP(c, sort_pairs_u32(c->d_keys[0], c->d_vals[0], c->d_keys[1], c->d_vals[1], (int64_t)entries, row_bits,
                                       c->d_sort_temp, &k_out, &v_out, nullptr, c->stream));
-            S2D_HIP(c, launch_tile_offsets(k_out, (uint32_t)entries, c->g.tiles_y, c->d_row_off, c->stream));
+            S2D_HIP(c, launch_tile_offsets(k_out, (uint32_t)entries, c->g.tiles_y, c->d_row_off, c->stream, (1u << kTlRowBits) - 1u));
         } else { // one tile row: the emission order is the row's order
             const uint32_t two[2] = {0u, (uint32_t)entries};
             S2D_HIP(c, hipMemcpyAsync(c->d_row_off, two, sizeof(two), hipMemcpyHostToDevice, c->stream));
             S2D_HIP(c, hipStreamSynchronize(c->stream)); // (`two` lives on this stack frame)
             v_out = c->d_vals[0];
+            k_out = c->d_keys[0];
         }
         // level 2: every row's entries by column, straight into the lists (the value buffer the sort finished with is free)
         uint32_t* list = v_out == c->d_vals[0] ? c->d_vals[1] : c->d_vals[0];
-        S2D_HIP(c, launch_tile_lists_from_rows(v_out, entries, c->d_rects, c->d_row_off, c->g, c->d_chunk_base, c->d_tl_hist,
+        S2D_HIP(c, launch_tile_lists_from_rows(v_out, k_out, entries, c->d_row_off, c->g, c->d_chunk_base, c->d_tl_hist,
                                                c->d_tile_off, list, c->stream));
         c->d_list = list;
     } else {

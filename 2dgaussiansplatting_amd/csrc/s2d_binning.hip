@@ -58,7 +58,9 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
 // binary search over the block's offsets (LDS) and the tile from the position inside that splat's rectangle (row-major,
 // the order the stable sort then keeps).  Consecutive lanes write consecutive words.  (One thread per splat writing its
 // ~20 pairs one after the other made every store instruction touch 64 different cache lines: 180 us at 20 M pairs.)
-// ROWS: one entry per (splat, tile row) instead of one per (splat, tile): key = the row, counts = rows per splat.
+// ROWS: one entry per (splat, tile row) instead of one per (splat, tile): counts = rows per splat, key = the row in the
+// low kTlRowBits bits with the rectangle's column range above it (bits 12..20 tx0, 21..29 tx1: the column pass of
+// s2d_tilelists.hip then reads its entries' ranges beside their splat indices instead of gathering rectangles).
 template <bool ROWS>
 __global__ __launch_bounds__(256) void emit_kernel(const TileRect* __restrict__ rects,
                                                    const uint32_t* __restrict__ offsets,
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(256) void emit_kernel(const TileRect* __restrict__ 
         const uint32_t o = base + q;
         if (o < capacity) {
             if (ROWS) {
-                keys[o] = r.ty0 + local;
+                keys[o] = (r.ty0 + local) | ((uint32_t)r.tx0 << kTlRowBits) | ((uint32_t)r.tx1 << (kTlRowBits + 9));
             } else {
                 const uint32_t ty = r.ty0 + local / w, tx = r.tx0 + local % w;
                 keys[o] = ty * (uint32_t)tiles_x + tx;
@@ -107,12 +109,12 @@ __global__ __launch_bounds__(256) void emit_kernel(const TileRect* __restrict__ 
 // tile_off[t] = first position p with sorted_keys[p] >= t; tile_off[num_tiles] = num_pairs.
 __global__ __launch_bounds__(256) void tile_offsets_kernel(const uint32_t* __restrict__ sorted_keys,
                                                            uint32_t num_pairs, int num_tiles,
-                                                           uint32_t* __restrict__ tile_off)
+                                                           uint32_t* __restrict__ tile_off, uint32_t key_mask)
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > num_pairs) return;
-    const int cur = (p < num_pairs) ? (int)sorted_keys[p] : num_tiles;
-    const int prev = (p > 0) ? (int)sorted_keys[p - 1] : -1;
+    const int cur = (p < num_pairs) ? (int)(sorted_keys[p] & key_mask) : num_tiles;
+    const int prev = (p > 0) ? (int)(sorted_keys[p - 1] & key_mask) : -1;
     for (int t = prev + 1; t <= cur; t++) tile_off[t] = p;
 }
 
@@ -145,11 +147,11 @@ hipError_t launch_emit_row_entries(const TileRect* rects, const uint32_t* row_of
 }
 
 hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, int num_tiles,
-                               uint32_t* tile_off, hipStream_t stream)
+                               uint32_t* tile_off, hipStream_t stream, uint32_t key_mask)
 {
     const uint32_t threads = num_pairs + 1;
     hipLaunchKernelGGL(tile_offsets_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, sorted_keys, num_pairs,
-                       num_tiles, tile_off);
+                       num_tiles, tile_off, key_mask);
     return hipGetLastError();
 }
 

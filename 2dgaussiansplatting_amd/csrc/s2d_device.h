@@ -167,15 +167,17 @@ hipError_t launch_emit_row_entries(const TileRect* rects, const uint32_t* row_of
                                    uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream);
 hipError_t launch_emit_pairs(const TileRect* rects, const uint32_t* offsets, const uint32_t* counts, int n, Geometry g,
                              uint32_t* keys, uint32_t* vals, uint32_t capacity, hipStream_t stream);
+// (key_mask: the bits of a key that count -- row entries carry their column range above the row)
 hipError_t launch_tile_offsets(const uint32_t* sorted_keys, uint32_t num_pairs, int num_tiles,
-                               uint32_t* tile_off, hipStream_t stream);
+                               uint32_t* tile_off, hipStream_t stream, uint32_t key_mask = 0xFFFFFFFFu);
 
 // tile lists in two levels (s2d_tilelists.hip): from the (splat, tile row) entries sorted by row -- `entries` holds the splat
 // indices, row_off[0 .. tiles_y] where each row's entries begin -- to tile_off[0 .. tiles] and the lists themselves.
 // Images of up to kTlMaxColumns tile columns.  workspace: tl_workspace_words(...) words; chunk_base: tiles_y + 1 words.
 constexpr int kTlMaxColumns = 512;
+constexpr int kTlRowBits = 12; // a row entry's key: tile row (H <= 65536) | tx0 << 12 | tx1 << 21 (nine bits each)
 size_t tl_workspace_words(uint64_t entries, int tiles_x, int tiles_y);
-hipError_t launch_tile_lists_from_rows(const uint32_t* entries, uint64_t num_entries, const TileRect* rects, const uint32_t* row_off,
+hipError_t launch_tile_lists_from_rows(const uint32_t* entries, const uint32_t* entry_keys, uint64_t num_entries, const uint32_t* row_off,
                                        Geometry g, uint32_t* chunk_base, uint32_t* workspace, uint32_t* tile_off, uint32_t* list,
                                        hipStream_t stream);
 

@@ -147,8 +147,10 @@ hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, int64_t n, uint
 // quarter of that, which it walks in 16 rounds of 64 consecutive items, so memory order ==
 // (block, wave, round, lane) order and a rank computed in that order is stable.
 // ---------------------------------------------------------------------------------------------------
+// dmask: the bits of the digit that belong to the key (the last pass of a key whose width is not a multiple of 8 must
+// not look at what the caller keeps above the key).
 __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t* __restrict__ keys, int64_t n,
-                                                                int shift, uint32_t* __restrict__ ghist, int nblk)
+                                                                int shift, uint32_t dmask, uint32_t* __restrict__ ghist, int nblk)
 {
     __shared__ uint32_t h[256];
     h[threadIdx.x] = 0;
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_hist_kernel(const uint32_t* 
 #pragma unroll
     for (int j = 0; j < kSortItemsPerThread; j++) {
         int64_t i = base + (int64_t)j * kSortBlock + threadIdx.x;
-        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & dmask], 1u);
     }
     __syncthreads();
     ghist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
                                                                    const uint32_t* __restrict__ vals_in,
                                                                    uint32_t* __restrict__ keys_out,
                                                                    uint32_t* __restrict__ vals_out, int64_t n,
-                                                                   int shift, const uint32_t* __restrict__ ghist_scanned,
+                                                                   int shift, uint32_t dmask, const uint32_t* __restrict__ ghist_scanned,
                                                                    int nblk, uint32_t* __restrict__ tile_first)
 {
     __shared__ uint32_t s_cnt[4 * 256]; // per-wave running digit counts, then per-wave exclusive bases
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
         const bool valid = i < n;
         key[j] = valid ? keys_in[i] : 0u;
         val[j] = valid ? vals_in[i] : 0u;
-        const uint32_t digit = (key[j] >> shift) & 255u;
+        const uint32_t digit = (key[j] >> shift) & dmask;
         // lanes of this wave holding the same digit
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
     for (int j = 0; j < kSortItemsPerThread; j++) {
         const int64_t i = wave_base + (int64_t)j * 64 + lane;
         if (i < n) {
-            const uint32_t digit = (key[j] >> shift) & 255u;
+            const uint32_t digit = (key[j] >> shift) & dmask;
             const uint32_t p = s_boff[digit] + s_cnt[w * 256 + digit] + rank[j];
             s_key[p] = key[j];
             s_val[p] = val[j];
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(kSortBlock) void radix_scatter_kernel(const uint32_
     const uint32_t count = (uint32_t)min((int64_t)kSortItemsPerBlock, n - block_base);
     for (uint32_t p = tid; p < count; p += kSortBlock) {
         const uint32_t k = s_key[p];
-        const uint32_t digit = (k >> shift) & 255u;
+        const uint32_t digit = (k >> shift) & dmask;
         const uint32_t dest = s_gbase[digit] + (p - s_boff[digit]);
         vals_out[dest] = s_val[p];
         if (LAST) {
@@ -329,16 +331,17 @@ hipError_t sort_pairs_u32(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, 
         uint32_t* ghist = temp;
         uint32_t* scan_temp = temp + 256 * nblk;
         for (int shift = 0; shift < key_bits; shift += 8) {
-            hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nblk), dim3(kSortBlock), 0, stream, kin, n, shift,
+            const uint32_t dmask = key_bits - shift >= 8 ? 255u : (1u << (key_bits - shift)) - 1u;
+            hipLaunchKernelGGL(radix_hist_kernel, dim3((unsigned)nblk), dim3(kSortBlock), 0, stream, kin, n, shift, dmask,
                                ghist, (int)nblk);
             hipError_t e = exclusive_scan_u32(ghist, ghist, 256 * nblk, scan_temp, nullptr, stream);
             if (e != hipSuccess) return e;
             if (tile_first && shift + 8 >= key_bits)
                 hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3((unsigned)nblk), dim3(kSortBlock), 0, stream, kin, vin,
-                                   kout, vout, n, shift, ghist, (int)nblk, tile_first);
+                                   kout, vout, n, shift, dmask, ghist, (int)nblk, tile_first);
             else
                 hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3((unsigned)nblk), dim3(kSortBlock), 0, stream, kin, vin,
-                                   kout, vout, n, shift, ghist, (int)nblk, tile_first);
+                                   kout, vout, n, shift, dmask, ghist, (int)nblk, tile_first);
             uint32_t* t;
             t = kin; kin = kout; kout = t;
             t = vin; vin = vout; vout = t;

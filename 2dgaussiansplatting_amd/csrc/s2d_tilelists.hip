@@ -8,7 +8,8 @@
 //   level 1, per (splat, tile ROW): a splat covers rows ty0..ty1 -- M entries, M = P / (columns per splat) ~ P / 4.5.  The
 //            entries are emitted in splat order and sorted by row with the generic stable radix sort (n = M): every tile
 //            row now has its splats in ascending order.
-//   level 2, per tile row, by COLUMN: an entry covers columns tx0..tx1 of its row.  The rows are cut into chunks of C
+//   level 2, per tile row, by COLUMN: an entry covers columns tx0..tx1 of its row (carried through the row sort in the
+//            upper bits of its key, so this level reads entries and ranges as two coalesced streams).  The rows are cut into chunks of C
 //            consecutive entries; a chunk's workgroup marks, in a bitmap in LDS (one bit per (column, entry)), which
 //            entries cover which column.  Pass A counts the entries per (chunk, column); a running sum down each row's
 //            chunks gives every chunk its place inside the column's tile list and the tile's size, whose exclusive scan
@@ -28,7 +29,8 @@ namespace s2d {
 #ifndef S2D_TL_CHUNK_WIDE
 #define S2D_TL_CHUNK_WIDE 256   // ... of up to kTlMaxColumns
 #endif
-constexpr int kTlStage = 3072; // pairs of a chunk staged in LDS before they are written out (more: straight to memory)
+// pairs of a chunk staged in LDS before they are written out: six per entry (a chunk with more writes straight to memory)
+template <int C> struct TlStage { static constexpr int value = 6 * C; };
 
 __host__ __device__ inline int tl_chunk_entries(int tiles_x) { return tiles_x <= 256 ? S2D_TL_CHUNK_NARROW : S2D_TL_CHUNK_WIDE; }
 
@@ -92,8 +94,11 @@ __global__ __launch_bounds__(256) void tl_chunk_desc_kernel(const uint32_t* __re
 }
 
 // Pass A: how many entries of the chunk cover each column (LDS counters).
+__device__ __forceinline__ int tl_tx0(uint32_t key) { return (int)((key >> kTlRowBits) & 511u); }
+__device__ __forceinline__ int tl_tx1(uint32_t key) { return (int)((key >> (kTlRowBits + 9)) & 511u); }
+
 template <int TXMAX>
-__global__ __launch_bounds__(256) void tl_hist_kernel(const uint32_t* __restrict__ entries, const TileRect* __restrict__ rects,
+__global__ __launch_bounds__(256) void tl_hist_kernel(const uint32_t* __restrict__ entry_keys,
                                                       const TlChunk* __restrict__ desc, int tiles_x, uint32_t* __restrict__ hist)
 {
     __shared__ uint32_t cnt[TXMAX];
@@ -102,8 +107,8 @@ __global__ __launch_bounds__(256) void tl_hist_kernel(const uint32_t* __restrict
     for (int tx = threadIdx.x; tx < tiles_x; tx += 256) cnt[tx] = 0u;
     __syncthreads();
     for (int e = threadIdx.x; e < c.cnt; e += 256) {
-        const TileRect r = rects[entries[c.e0 + e]];
-        for (int tx = r.tx0; tx <= (int)r.tx1; tx++) atomicAdd(cnt + tx, 1u);
+        const uint32_t key = entry_keys[c.e0 + e];
+        for (int tx = tl_tx0(key); tx <= tl_tx1(key); tx++) atomicAdd(cnt + tx, 1u);
     }
     __syncthreads();
     for (int tx = threadIdx.x; tx < tiles_x; tx += 256) hist[c.hist_base + (uint32_t)tx] = cnt[tx];
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void tl_column_prefix_kernel(uint32_t* __restr
 // entries, one w) hitting different columns hit different banks, and a thread walking one column over w reads beside its
 // neighbours' columns.
 template <int TXMAX, int C>
-__global__ __launch_bounds__(256) void tl_scatter_kernel(const uint32_t* __restrict__ entries, const TileRect* __restrict__ rects,
+__global__ __launch_bounds__(256) void tl_scatter_kernel(const uint32_t* __restrict__ entries, const uint32_t* __restrict__ entry_keys,
                                                          const TlChunk* __restrict__ desc, const uint32_t* __restrict__ place,
                                                          const uint32_t* __restrict__ tile_off, int tiles_x,
                                                          uint32_t* __restrict__ list)
@@ -140,6 +145,7 @@ __global__ __launch_bounds__(256) void tl_scatter_kernel(const uint32_t* __restr
     __shared__ uint16_t pre[words * TXMAX];  // per column: entries covering it in front of each word
     __shared__ uint32_t boff[TXMAX + 1];     // start of each column's run in the chunk's output
     __shared__ uint32_t gbase[TXMAX];        // the column's position in its tile list for this chunk
+    constexpr int kTlStage = TlStage<C>::value;
     __shared__ uint32_t stage[kTlStage];     // the chunk's output in column order ...
     __shared__ uint16_t stage_col[kTlStage]; // ... and the column of each element
     __shared__ uint32_t s_wave[4];
@@ -148,16 +154,14 @@ __global__ __launch_bounds__(256) void tl_scatter_kernel(const uint32_t* __restr
     const int t = threadIdx.x;
     constexpr int kPer = C / 256; // entries per thread: their indices and rectangles stay in registers between the phases
     uint32_t my_splat[kPer];
-    TileRect my_rect[kPer];
+    int my_tx0[kPer], my_tx1[kPer];
 #pragma unroll
     for (int k = 0; k < kPer; k++) {
         const int e = k * 256 + t;
         my_splat[k] = e < c.cnt ? entries[c.e0 + e] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < kPer; k++) {
-        my_rect[k].tx0 = 1; my_rect[k].tx1 = 0; my_rect[k].ty0 = 0; my_rect[k].ty1 = 0; // covers nothing
-        if (k * 256 + t < c.cnt) my_rect[k] = rects[my_splat[k]];
+        const uint32_t key = e < c.cnt ? entry_keys[c.e0 + e] : (1u << kTlRowBits); // (tx0 = 1 > tx1 = 0: covers nothing)
+        my_tx0[k] = tl_tx0(key);
+        my_tx1[k] = tl_tx1(key);
     }
     for (int q = t; q < words * tiles_x; q += 256) bm[q] = 0u;
     __syncthreads();
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void tl_scatter_kernel(const uint32_t* __restr
         const int e = k * 256 + t;
         uint32_t* row = bm + (e >> 5) * tiles_x;
         const uint32_t bit = 1u << (e & 31);
-        for (int tx = my_rect[k].tx0; tx <= (int)my_rect[k].tx1; tx++) atomicOr(row + tx, bit);
+        for (int tx = my_tx0[k]; tx <= my_tx1[k]; tx++) atomicOr(row + tx, bit);
     }
     __syncthreads();
     // per column: the count in front of every word, the total, the base position
@@ -214,10 +218,9 @@ __global__ __launch_bounds__(256) void tl_scatter_kernel(const uint32_t* __restr
     for (int k = 0; k < kPer; k++) {
         const int e = k * 256 + t;
         const uint32_t splat = my_splat[k];
-        const TileRect r = my_rect[k];
         const int w = e >> 5;
         const uint32_t below = (1u << (e & 31)) - 1u;
-        for (int tx = r.tx0; tx <= (int)r.tx1; tx++) {
+        for (int tx = my_tx0[k]; tx <= my_tx1[k]; tx++) {
             const uint32_t rank = (uint32_t)pre[w * tiles_x + tx] + (uint32_t)__popc(bm[w * tiles_x + tx] & below);
             if (staged) {
                 stage[boff[tx] + rank] = splat;
@@ -243,7 +246,7 @@ size_t tl_workspace_words(uint64_t entries, int tiles_x, int tiles_y)
     return chunks * (size_t)tiles_x + tiles + scan_temp_words((int64_t)tiles) + chunks * (sizeof(TlChunk) / sizeof(uint32_t)) + 8;
 }
 
-hipError_t launch_tile_lists_from_rows(const uint32_t* entries, uint64_t num_entries, const TileRect* rects, const uint32_t* row_off,
+hipError_t launch_tile_lists_from_rows(const uint32_t* entries, const uint32_t* entry_keys, uint64_t num_entries, const uint32_t* row_off,
                                        Geometry g, uint32_t* chunk_base, uint32_t* workspace, uint32_t* tile_off, uint32_t* list,
                                        hipStream_t stream)
 {
@@ -259,19 +262,19 @@ hipError_t launch_tile_lists_from_rows(const uint32_t* entries, uint64_t num_ent
     hipLaunchKernelGGL(tl_chunk_desc_kernel, dim3((chunks + 255) / 256), dim3(256), 0, stream, chunk_base, row_off, g.tiles_x, g.tiles_y, C,
                        chunks, desc);
     if (g.tiles_x <= 256)
-        hipLaunchKernelGGL((tl_hist_kernel<256>), dim3(chunks), dim3(256), 0, stream, entries, rects, desc, g.tiles_x, hist);
+        hipLaunchKernelGGL((tl_hist_kernel<256>), dim3(chunks), dim3(256), 0, stream, entry_keys, desc, g.tiles_x, hist);
     else
-        hipLaunchKernelGGL((tl_hist_kernel<kTlMaxColumns>), dim3(chunks), dim3(256), 0, stream, entries, rects, desc, g.tiles_x, hist);
+        hipLaunchKernelGGL((tl_hist_kernel<kTlMaxColumns>), dim3(chunks), dim3(256), 0, stream, entry_keys, desc, g.tiles_x, hist);
     hipLaunchKernelGGL(tl_column_prefix_kernel, dim3((g.tiles_x + 255) / 256, g.tiles_y), dim3(256), 0, stream, hist, chunk_base, g.tiles_x,
                        tile_count);
     // tile_off[t] = pairs of the tiles before t; tile_off[tiles] = all of them (the scan's total)
     hipError_t e = exclusive_scan_u32(tile_count, tile_off, (int64_t)g.num_tiles, scan_temp, tile_off + g.num_tiles, stream);
     if (e != hipSuccess) return e;
     if (g.tiles_x <= 256)
-        hipLaunchKernelGGL((tl_scatter_kernel<256, S2D_TL_CHUNK_NARROW>), dim3(chunks), dim3(256), 0, stream, entries, rects, desc, hist,
+        hipLaunchKernelGGL((tl_scatter_kernel<256, S2D_TL_CHUNK_NARROW>), dim3(chunks), dim3(256), 0, stream, entries, entry_keys, desc, hist,
                            tile_off, g.tiles_x, list);
     else
-        hipLaunchKernelGGL((tl_scatter_kernel<kTlMaxColumns, S2D_TL_CHUNK_WIDE>), dim3(chunks), dim3(256), 0, stream, entries, rects, desc,
+        hipLaunchKernelGGL((tl_scatter_kernel<kTlMaxColumns, S2D_TL_CHUNK_WIDE>), dim3(chunks), dim3(256), 0, stream, entries, entry_keys, desc,
                            hist, tile_off, g.tiles_x, list);
     return hipGetLastError();
 }
