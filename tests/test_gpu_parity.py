@@ -1324,6 +1324,31 @@ def a_init_splats(W, H, n):
         return t.get_splats()
 
 
+def test_get_stats_respects_the_callers_struct_size():
+    """s2d_stats starts with the size the CALLER was compiled with: the library writes no more than that (a caller built
+    against a shorter, older struct is not overrun) and refuses a size below the struct's first version."""
+    import ctypes as C
+    L = S2D.load_library()
+    with S2D.Trainer(64, 48, 10) as t:
+        t.set_target_synthetic()
+        t.init()
+        t.step(2)
+        full = C.sizeof(S2D._Stats)
+        buf = (C.c_uint8 * (full + 64))()
+        for i in range(len(buf)):
+            buf[i] = 0xAB
+        st = C.cast(buf, C.POINTER(S2D._Stats))
+        shorter = S2D._Stats.bwd_quadrant_execs.offset + 8            # the struct as ABI version 2 introduced it
+        st.contents.struct_size = shorter
+        assert L.s2d_get_stats(t._h, st) == 0
+        assert st.contents.iterations == 2 and st.contents.rebins >= 1 and st.contents.struct_size == shorter
+        assert all(b == 0xAB for b in bytes(buf)[shorter:])         # nothing behind the caller's struct was touched
+        st.contents.struct_size = shorter - 8
+        assert L.s2d_get_stats(t._h, st) == 1                      # S2D_E_INVALID
+        st.contents.struct_size = full + 32                        # a NEWER caller: gets what this library knows, sized to it
+        assert L.s2d_get_stats(t._h, st) == 0 and st.contents.struct_size == full
+
+
 def test_backward_refuses_a_framebuffer_the_fused_launch_did_not_store():
     """s2d_forward_backward with S2D_FB_SKIP_IMAGE leaves an OLDER frame in image0: a following s2d_backward, which reads
     image0, must refuse (S2D_E_STATE) instead of differentiating against that frame; with the image stored it runs."""
