@@ -57,6 +57,11 @@
 #define OP_MAD64(n) "v_mad_u64_u32 v[40:41], s[20:21], %" #n ", %8, v[40:41]\n"
 #define OP_MUL_THEN_S(n) "v_mul_f32 %" #n ", %" #n ", %8\n s_and_b32 s24, s24, s25\n"
 #define OP_MUL_THEN_NOP(n) "v_mul_f32 %" #n ", %" #n ", %8\n s_nop 0\n"
+#define OP_MUL_THEN_2S(n) "v_mul_f32 %" #n ", %" #n ", %8\n s_and_b32 s24, s24, s25\n s_and_b32 s20, s20, s25\n"
+#define OP_S_AND(n) "s_and_b32 s24, s24, s25\n"
+#define OP_S_AND64(n) "s_and_b64 s[20:21], s[20:21], s[22:23]\n"
+#define OP_S_FF1(n) "s_ff1_i32_b64 s24, s[20:21]\n"
+#define OP_S_BRANCH(n) "s_cmp_eq_u32 s25, 12345\n s_cbranch_scc1 1\n s_nop 0\n"
 
 KERNEL(k_mul_x8, X8(OP_MUL))
 KERNEL(k_mul_x1, X1(OP_MUL))
@@ -88,6 +93,14 @@ KERNEL(k_mulsgpr_x8, X8(OP_MUL_SGPR))
 KERNEL(k_mullit_x8, X8(OP_MUL_LIT))
 KERNEL(k_mul_s_x8, ALL8(OP_MUL_THEN_S))
 KERNEL(k_mul_nop_x8, ALL8(OP_MUL_THEN_NOP))
+KERNEL(k_mul_2s_x8, ALL8(OP_MUL_THEN_2S))
+// two / four v_mul per s_and
+KERNEL(k_mul2_s, OP_MUL(0) OP_MUL(1) OP_S_AND(0) OP_MUL(2) OP_MUL(3) OP_S_AND(0) OP_MUL(4) OP_MUL(5) OP_S_AND(0) OP_MUL(6) OP_MUL(7) OP_S_AND(0))
+KERNEL(k_mul4_s, OP_MUL(0) OP_MUL(1) OP_MUL(2) OP_MUL(3) OP_S_AND(0) OP_MUL(4) OP_MUL(5) OP_MUL(6) OP_MUL(7) OP_S_AND(0))
+KERNEL(k_s_and, X8(OP_S_AND))
+KERNEL(k_s_and64, X8(OP_S_AND64))
+KERNEL(k_s_ff1, X8(OP_S_FF1))
+KERNEL(k_s_branch, ALL8(OP_S_BRANCH))
 KERNEL(k_swap32_x8, "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
                     "v_permlane32_swap_b32 %0, %2\n v_permlane32_swap_b32 %1, %3\n v_permlane32_swap_b32 %4, %6\n v_permlane32_swap_b32 %5, %7\n"
                     "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7\n"
@@ -204,7 +217,10 @@ int main(int argc, char** argv)
         {"v_fma_f32 x8, EXEC = rows 0 and 2", k_fma_exec_rows02}, {"v_fma_f32 x8, EXEC = lane 0", k_fma_exec_one},
         {"v_pk_mul_f32 x8", k_pkmul_x8}, {"v_pk_add_f32 x8", k_pkadd_x8}, {"v_pk_fma_f32 x8", k_pkfma_x8}, {"v_pk_mov_b32 x8", k_pkmov_x8},
     };
-    const std::vector<K> mixed = {{"(v_mul_f32 + s_and_b32) pairs", k_mul_s_x8}, {"(v_mul_f32 + s_nop) pairs", k_mul_nop_x8}};
+    const std::vector<K> mixed = {{"(v_mul_f32 + s_and_b32) pairs", k_mul_s_x8}, {"(v_mul_f32 + s_nop) pairs", k_mul_nop_x8},
+                                  {"(v_mul_f32 + 2 s_and_b32), per v_mul", k_mul_2s_x8}, {"(2 v_mul_f32 + s_and_b32), per v_mul", k_mul2_s},
+                                  {"(4 v_mul_f32 + s_and_b32), per v_mul", k_mul4_s}, {"(s_cmp + s_cbranch not taken), per pair", k_s_branch}};
+    const std::vector<K> scalar = {{"s_and_b32 alone", k_s_and}, {"s_and_b64 alone", k_s_and64}, {"s_ff1_i32_b64 alone", k_s_ff1}};
     printf("left: issue interval seen by the oldest wave of a SIMD (it wins arbitration); right: what the SIMD spends per\n"
            "wave-instruction when W waves per SIMD run the same stream (whole-kernel time)\n");
     printf("%-32s %8s | %s\n", "opcode", "MHz", "oldest wave: cycles/instr at W=1,2,4,8  ||  SIMD cycles/instr (kernel time x clock / instrs / W) at W=1,2,4,8");
@@ -234,6 +250,7 @@ int main(int argc, char** argv)
     };
     for (const K& k : kernels) run(k, 16);
     for (const K& k : mixed) run(k, 8); // per v_mul (each followed by one SALU instruction)
+    for (const K& k : scalar) run(k, 16);
     for (int mode = 0; mode < 2; mode++) {
         double wave_cyc[4], mhz = 0;
         int wi = 0;
