@@ -396,21 +396,21 @@ __device__ __forceinline__ float wave_sum8_lds(float* sw, int lane, float a0, fl
     return t;
 }
 
-// num / den, correctly rounded, from the hardware reciprocal r = v_rcp_f32(den) (1 ulp) shared by several
-// numerators: quotient estimate, then two corrections q += (num - den*q) * r whose residuals are exact (fma).  The
-// first brings q to within half an ulp up to a 1e-7 ulp sliver, the second settles that sliver; a Newton step on
-// the reciprocal itself (as in the compiler's IEEE division sequence) changes nothing measurable -- same parity
-// statistics with and without it (tools/gpu_grad_stats.py) -- and is left out.  No per-division scaling for
-// denormal / huge operands either: they cannot occur here (den in [1e-15, 1], |num| <~ 1).
+// num / den as IEEE division would round it, from the hardware reciprocal r = v_rcp_f32(den) (1 ulp) shared by several
+// numerators: quotient estimate, then ONE correction q += (num - den*q) * r whose residual is exact (fma).  The estimate
+// is off by up to ~1.5 ulp; the corrected value is the correctly rounded quotient unless the true quotient lies within
+// ~3e-7 ulp of a rounding boundary -- 0 or 1 of 20 M random (S, 1 - alpha) pairs differ from IEEE division, whether r is
+// the rounded reciprocal or one ulp to either side of it, and a second or third correction changes none of them
+// (tools/check_recip_division.py).  Rounds 1-3 applied two corrections: six more instructions per executed (wave,
+// entry), same parity statistics, -2.9 % (profiles/r03/ab_one_division_correction.txt).  No per-division scaling for
+// denormal / huge operands: they cannot occur here (den in [1e-15, 1], |num| <~ 1).
 // The quotient must be the one the reference computes:
 // c*T - S/(1-alpha) cancels down to a T_final-sized remainder, which magnifies a last-place difference in the
 // quotient by T/T_final (10^3..10^5 in flat image regions).
 __device__ __forceinline__ float div_by_recip(float num, float den, float r)
 {
-    float q = num * r;
-    q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
-    q = __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
-    return q;
+    const float q = num * r;
+    return __builtin_fmaf(__builtin_fmaf(-den, q, num), r, q);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -610,11 +610,10 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
                     g_b = dLb * dC_dc;
                     // S / (1 - alpha + 1e-15), main.cpp:627-628: three quotients over one denominator (div_by_recip)
                     const float den = 1.0f - alpha + 1.0e-15f;
-                    const float rd = __builtin_amdgcn_rcpf(den); // 1 ulp; the two corrections below do the rest
+                    const float rd = __builtin_amdgcn_rcpf(den); // 1 ulp; the correction below does the rest
                     const f2 S_rg = fin_rg - crg;                                    // S = final - colour
                     const f2 nden2 = mk2(-den, -den), rd2 = mk2(rd, rd);
                     f2 q_rg = S_rg * rd;
-                    q_rg = fma2(fma2(nden2, q_rg, S_rg), rd2, q_rg);
                     q_rg = fma2(fma2(nden2, q_rg, S_rg), rd2, q_rg);
                     const f2 dCa_rg = Trg - q_rg;
                     const float dCa_b = Tb - div_by_recip(fin.z - cb, den, rd);
