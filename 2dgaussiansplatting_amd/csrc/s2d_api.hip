@@ -1144,3 +1144,12 @@ done:
 }
 
 } // extern "C"
+
+#ifdef S2D_EXP_CLOCK
+// diagnostic build only: the four s_memrealtime stamps per tile the fused raster kernel left behind the lane masks
+extern "C" int s2d_exp_read_probe(s2d_ctx* c, unsigned long long* out, int tiles)
+{
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
+    return hipMemcpy(out, c->d_wave_masks + (size_t)c->pairs * 4, (size_t)tiles * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif

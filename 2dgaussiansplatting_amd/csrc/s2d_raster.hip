@@ -750,9 +750,16 @@ __global__ __launch_bounds__(256, 8) void raster_fused_kernel(const uint32_t* __
     const int tile = tile_of_block(blockIdx.x, g);
     if (tile < 0) return;
     const TileCtx c = tile_ctx(tile, g);
+#ifdef S2D_EXP_CLOCK
+    unsigned long long* const probe = wave_masks + (size_t)tile_off[g.num_tiles] * 4 + (size_t)tile * 4;
+    if (threadIdx.x == 0) probe[0] = __builtin_amdgcn_s_memrealtime();
+#endif
     f2 crg;
     float cb;
     forward_tile<false, EXACT>(*reinterpret_cast<FwdShared*>(smem), c, tile_off, list, proj, wave_masks, g, nullptr, crg, cb);
+#ifdef S2D_EXP_CLOCK
+    if (threadIdx.x == 0) probe[1] = __builtin_amdgcn_s_memrealtime();
+#endif
     float4 fin = make_float4(crg.x, crg.y, cb, 1.0f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
     if (HALF) { // what the backward pass would read back from the fp16 framebuffer
         const __half2 a = __floats2half2_rn(fin.x, fin.y), b = __floats2half2_rn(fin.z, fin.w);
@@ -768,6 +775,12 @@ __global__ __launch_bounds__(256, 8) void raster_fused_kernel(const uint32_t* __
     __syncthreads(); // the backward walk re-uses the LDS the forward walk's last flag exchange may still be reading
     backward_tile<false, NEED_OP, DET, EXACT>(*reinterpret_cast<BwdShared<DET>*>(smem), c, fin, ref, tile_off, list, proj,
                                               wave_masks, grads, tile_sqerr, g, det, nullptr, sq);
+#ifdef S2D_EXP_CLOCK
+    if (threadIdx.x == 0) probe[2] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) probe[3] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // Deterministic mode: gradient of splat i = sum of the partials its tiles stored this iteration, in emission
