@@ -59,6 +59,9 @@
 #define OP_MUL_THEN_NOP(n) "v_mul_f32 %" #n ", %" #n ", %8\n s_nop 0\n"
 #define OP_MUL_THEN_2S(n) "v_mul_f32 %" #n ", %" #n ", %8\n s_and_b32 s24, s24, s25\n s_and_b32 s20, s20, s25\n"
 #define OP_S_AND(n) "s_and_b32 s24, s24, s25\n"
+#define OP_CMP_CND_VCC(n) "v_cmp_lt_f32 vcc, %" #n ", %8\n s_nop 1\n v_cndmask_b32 %" #n ", %" #n ", %9, vcc\n"
+#define OP_CMP_CND_SGPR(n) "v_cmp_lt_f32 s[20:21], %" #n ", %8\n s_nop 1\n v_cndmask_b32 %" #n ", %" #n ", %9, s[20:21]\n"
+#define OP_CMP_CND_SGPR_ROT(n) "v_cmp_lt_f32 s[22:23], %" #n ", %8\n v_cmp_lt_f32 s[20:21], %" #n ", %9\n v_cndmask_b32 %" #n ", %" #n ", %9, s[22:23]\n v_cndmask_b32 %" #n ", %" #n ", %8, s[20:21]\n"
 #define OP_S_AND64(n) "s_and_b64 s[20:21], s[20:21], s[22:23]\n"
 #define OP_S_FF1(n) "s_ff1_i32_b64 s24, s[20:21]\n"
 #define OP_S_BRANCH(n) "s_cmp_eq_u32 s25, 12345\n s_cbranch_scc1 1\n s_nop 0\n"
@@ -98,6 +101,9 @@ KERNEL(k_mul_2s_x8, ALL8(OP_MUL_THEN_2S))
 KERNEL(k_mul2_s, OP_MUL(0) OP_MUL(1) OP_S_AND(0) OP_MUL(2) OP_MUL(3) OP_S_AND(0) OP_MUL(4) OP_MUL(5) OP_S_AND(0) OP_MUL(6) OP_MUL(7) OP_S_AND(0))
 KERNEL(k_mul4_s, OP_MUL(0) OP_MUL(1) OP_MUL(2) OP_MUL(3) OP_S_AND(0) OP_MUL(4) OP_MUL(5) OP_MUL(6) OP_MUL(7) OP_S_AND(0))
 KERNEL(k_s_and, X8(OP_S_AND))
+KERNEL(k_cmpcnd_vcc, ALL8(OP_CMP_CND_VCC))
+KERNEL(k_cmpcnd_sgpr, ALL8(OP_CMP_CND_SGPR))
+KERNEL(k_cmpcnd_sgpr_rot, ALL8(OP_CMP_CND_SGPR_ROT))
 KERNEL(k_s_and64, X8(OP_S_AND64))
 KERNEL(k_s_ff1, X8(OP_S_FF1))
 KERNEL(k_s_branch, ALL8(OP_S_BRANCH))
@@ -219,7 +225,10 @@ int main(int argc, char** argv)
     };
     const std::vector<K> mixed = {{"(v_mul_f32 + s_and_b32) pairs", k_mul_s_x8}, {"(v_mul_f32 + s_nop) pairs", k_mul_nop_x8},
                                   {"(v_mul_f32 + 2 s_and_b32), per v_mul", k_mul_2s_x8}, {"(2 v_mul_f32 + s_and_b32), per v_mul", k_mul2_s},
-                                  {"(4 v_mul_f32 + s_and_b32), per v_mul", k_mul4_s}, {"(s_cmp + s_cbranch not taken), per pair", k_s_branch}};
+                                  {"(4 v_mul_f32 + s_and_b32), per v_mul", k_mul4_s}, {"(s_cmp + s_cbranch not taken), per pair", k_s_branch},
+                                  {"(v_cmp -> vcc, s_nop 1, v_cndmask vcc), per pair", k_cmpcnd_vcc},
+                                  {"(v_cmp -> sgpr pair, s_nop 1, v_cndmask sgpr), per pair", k_cmpcnd_sgpr}};
+    const std::vector<K> mixed2 = {{"2 x (v_cmp -> sgpr, v_cndmask sgpr) interleaved, per pair", k_cmpcnd_sgpr_rot}};
     const std::vector<K> scalar = {{"s_and_b32 alone", k_s_and}, {"s_and_b64 alone", k_s_and64}, {"s_ff1_i32_b64 alone", k_s_ff1}};
     printf("left: issue interval seen by the oldest wave of a SIMD (it wins arbitration); right: what the SIMD spends per\n"
            "wave-instruction when W waves per SIMD run the same stream (whole-kernel time)\n");
@@ -250,6 +259,7 @@ int main(int argc, char** argv)
     };
     for (const K& k : kernels) run(k, 16);
     for (const K& k : mixed) run(k, 8); // per v_mul (each followed by one SALU instruction)
+    for (const K& k : mixed2) run(k, 16);
     for (const K& k : scalar) run(k, 16);
     for (int mode = 0; mode < 2; mode++) {
         double wave_cyc[4], mhz = 0;
