@@ -435,8 +435,8 @@ struct DetSlots {
 };
 
 // LDS of the backward walk.  Entries per staged batch: 64, or 32 in deterministic mode, whose four per-wave slot sets would
-// otherwise lift the workgroup from 19.5 to 25.7 KB of LDS -- six instead of eight workgroups per CU, which alone costs
-// ~14 % (profiles/r03/r03_bound_experiments.txt); with half-size batches it is 17.5 KB.  The forward walk stages 64 either
+// otherwise lift the workgroup from 18.9 to ~25 KB of LDS -- six instead of eight workgroups per CU, which alone costs
+// ~14 % (profiles/r03/r03_bound_experiments.txt); with half-size batches it is 17.1 KB.  The forward walk stages 64 either
 // way: the lane masks it leaves behind are indexed by list position, and a walk that looks at its pixels' throughput
 // every 32 entries stops no later than one that looks every 64.
 template <bool DET>
