@@ -11,6 +11,7 @@ The package name starts with a digit, so import it with
 """
 import ctypes as C
 import os
+import warnings
 
 import numpy as np
 
@@ -78,6 +79,7 @@ ABI_SYMBOLS = [
     "s2d_multi_create", "s2d_multi_destroy", "s2d_multi_last_error", "s2d_multi_device_count", "s2d_multi_set_target",
     "s2d_multi_set_target_synthetic", "s2d_multi_init_splats", "s2d_multi_set_splats", "s2d_multi_get_splats",
     "s2d_multi_set_adam", "s2d_multi_get_adam", "s2d_multi_step", "s2d_multi_get_image", "s2d_multi_exchange_info", "s2d_multi_forward",
+    "s2d_multi_device_info", "s2d_multi_set_stall_timeout", "s2d_test_multi_stall",
 ]
 
 _lib = None
@@ -89,6 +91,38 @@ def hip_runtimes_mapped():
         with open("/proc/self/maps") as f:
             return sorted({line.split()[-1] for line in f if "libamdhip64" in line})
     except OSError:
+        return []
+
+
+def _elf_dynamic_strings(path, tag):
+    """Strings of the given dynamic-section tag (1 = DT_NEEDED, 14 = DT_SONAME) of a 64-bit little-endian ELF file; [] when
+    the file cannot be read that way."""
+    import struct
+    try:
+        with open(path, "rb") as f:
+            head = f.read(64)
+            if head[:6] != b"\x7fELF\x02\x01":
+                return []
+            shoff, = struct.unpack_from("<Q", head, 0x28)
+            shentsize, shnum = struct.unpack_from("<HH", head, 0x3A)
+            f.seek(shoff)
+            sh = f.read(shentsize * shnum)
+            out = []
+            for k in range(shnum):
+                _, typ, _, _, off, size, link, _, _, entsize = struct.unpack_from("<IIQQQQIIQQ", sh, k * shentsize)
+                if typ != 6:  # SHT_DYNAMIC
+                    continue
+                _, _, _, _, stroff, strsize, _, _, _, _ = struct.unpack_from("<IIQQQQIIQQ", sh, link * shentsize)
+                f.seek(off)
+                dyn = f.read(size)
+                f.seek(stroff)
+                strtab = f.read(strsize)
+                for j in range(0, size, 16):
+                    t, v = struct.unpack_from("<qQ", dyn, j)
+                    if t == tag:
+                        out.append(strtab[v:strtab.index(b"\0", v)].decode())
+            return out
+    except (OSError, struct.error, ValueError):
         return []
 
 
@@ -127,7 +161,20 @@ def _bind_process_hip_runtime():
             if os.path.exists(cand):
                 path = cand
     if path:
-        C.CDLL(path, mode=C.RTLD_GLOBAL)
+        needed = _elf_dynamic_strings(os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsplat2d_hip.so"), 1)  # DT_NEEDED
+        soname = _elf_dynamic_strings(path, 14)  # DT_SONAME
+        want = [x for x in needed if x.startswith("libamdhip64")]
+        if choice in ("auto", "torch") and want and soname and soname[0] not in want:
+            # the bundled runtime would not satisfy our DT_NEEDED entry: mapping it would put TWO runtimes into a process
+            # that never imports torch and works with the system's alone
+            warnings.warn("2dgaussiansplatting_amd: %s has SONAME %s, libsplat2d_hip.so needs %s: leaving the choice of the HIP "
+                          "runtime to the dynamic linker (import torch first if this process uses both)" % (path, soname[0], want[0]))
+            return
+        try:
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+        except OSError as e:
+            warnings.warn("2dgaussiansplatting_amd: could not pre-map the HIP runtime %s (%s): leaving the choice to the dynamic "
+                          "linker" % (path, e))
 
 
 def load_library(path=None):
@@ -216,6 +263,9 @@ def load_library(path=None):
     sig("s2d_multi_get_image", [vp, vp])
     sig("s2d_multi_exchange_info", [vp, vp])
     sig("s2d_multi_forward", [vp])
+    sig("s2d_multi_device_info", [vp, i32, vp, vp, vp, C.c_char_p, i32, C.c_char_p, i32])
+    sig("s2d_multi_set_stall_timeout", [vp, i32])
+    sig("s2d_test_multi_stall", [vp, i32, i32, i32])
     if path == _build.LIB_PATH:
         _lib = L
     return L
@@ -525,6 +575,23 @@ class MultiTrainer:
         a = np.zeros((self.H, self.W, 4), dtype=np.float32)
         self._ck(self.L.s2d_multi_get_image(self._h, _p(a)))
         return a
+
+    def device_info(self, rank):
+        """Which GPU runs which rows: {rank, device, row_begin, row_end, pci_bus_id, name} of one rank."""
+        dev, r0, r1 = C.c_int32(), C.c_int32(), C.c_int32()
+        pci, name = C.create_string_buffer(64), C.create_string_buffer(256)
+        self._ck(self.L.s2d_multi_device_info(self._h, int(rank), C.byref(dev), C.byref(r0), C.byref(r1), pci, 64, name, 256))
+        return {"rank": int(rank), "device": dev.value, "row_begin": r0.value, "row_end": r1.value,
+                "pci_bus_id": pci.value.decode(), "name": name.value.decode()}
+
+    def set_stall_timeout(self, milliseconds):
+        """Every wait of one rank for another (and for its own stream) gives up after this long: step() then raises
+        S2D_E_STATE naming the rank instead of hanging (0 = wait without bound)."""
+        self._ck(self.L.s2d_multi_set_stall_timeout(self._h, int(milliseconds)))
+
+    def test_stall(self, rank, iteration, milliseconds):
+        """Failure injection (include/splat2d_test.h): rank `rank` stops answering at `iteration`."""
+        self._ck(self.L.s2d_test_multi_stall(self._h, int(rank), int(iteration), int(milliseconds)))
 
     def exchange_info(self):
         """scheme, gradient rows swapped per iteration (all ranks), state rows handed over, splats held (all ranks)."""

@@ -20,6 +20,7 @@
 // S2D_MULTI_SHARE_GPU (rehearsal on a box with fewer GPUs than ranks): all ranks on the first listed device; the peer
 // copies become plain device copies, the all-reduce is staged through pinned host memory in rank order.
 #include "../../include/splat2d.h"
+#include "../../include/splat2d_test.h"
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
@@ -27,10 +28,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -87,12 +90,16 @@ bool load_rccl(Rccl* r, std::string* why)
     return true;
 }
 
-// Reusable barrier of the rank threads; abort() releases everybody for good once a rank has failed.
+// Reusable barrier of the rank threads; abort() releases everybody for good once a rank has failed.  A wait is bounded:
+// a rank that does not arrive within `timeout_ms` (it stopped answering -- stuck in a device wait, or dead) breaks the
+// barrier for everybody instead of leaving the others asleep, and `timed_out` says so.
 struct Barrier {
     std::mutex m;
     std::condition_variable cv;
     int n = 1, waiting = 0, generation = 0;
     std::atomic<bool> broken{false};
+    std::atomic<bool> timed_out{false};
+    std::atomic<int> timeout_ms{0}; // 0: wait without bound
     void wait()
     {
         std::unique_lock<std::mutex> lk(m);
@@ -102,8 +109,16 @@ struct Barrier {
             waiting = 0;
             generation++;
             cv.notify_all();
-        } else {
-            cv.wait(lk, [&] { return gen != generation || broken; });
+            return;
+        }
+        const auto ready = [&] { return gen != generation || broken; };
+        const int ms = timeout_ms.load();
+        if (ms <= 0) {
+            cv.wait(lk, ready);
+        } else if (!cv.wait_for(lk, std::chrono::milliseconds(ms), ready)) {
+            timed_out = true;
+            broken = true;
+            cv.notify_all();
         }
     }
     void abort()
@@ -116,6 +131,7 @@ struct Barrier {
     {
         std::lock_guard<std::mutex> lk(m);
         broken = false;
+        timed_out = false;
         waiting = 0;
     }
 };
@@ -123,6 +139,21 @@ struct Barrier {
 enum Command { CMD_NONE = 0, CMD_STEP, CMD_HOLD, CMD_FORWARD, CMD_QUIT };
 enum Scheme { SCHEME_NONE = 0, SCHEME_OWNERSHIP = 1, SCHEME_REPLICATED = 2 };
 constexpr int kStopped = -1; // a rank that stopped because another one failed (never reported to the caller)
+
+// What a rank thread is doing, for the report when one stops answering (s2d_multi_last_error names it).
+enum Phase { PH_IDLE = 0, PH_RASTER, PH_EXCHANGE, PH_ALLREDUCE, PH_ADAM, PH_REFRESH, PH_DRAIN, PH_HOLD, PH_FORWARD, PH_DONE };
+const char* phase_name(int p)
+{
+    static const char* const names[] = {"idle", "raster launch", "gradient exchange", "all-reduce", "Adam step", "hold-set refresh",
+                                        "waiting for its stream", "making the hold sets", "forward", "done"};
+    return p >= 0 && p <= PH_DONE ? names[p] : "?";
+}
+
+struct Progress {                 // one per rank, written by its thread only
+    std::atomic<uint64_t> ticks{0};   // bumped at every phase change: the watchdog of run_command looks for movement
+    std::atomic<int> phase{PH_IDLE};
+    std::atomic<int> iteration{0};
+};
 
 // Device array that only grows (freed and re-allocated while the rank's stream is idle).
 template <typename T>
@@ -190,7 +221,10 @@ struct s2d_multi {
     std::vector<s2d_ctx*> ctx;
     std::vector<int> row_begin, row_end;
     Rccl rccl;
-    std::vector<ncclComm_t> comms;
+    // One communicator per rank.  A slot is emptied (exchange(nullptr)) by whoever aborts or destroys it, so exactly one
+    // thread ever frees a communicator and nobody can pick up a freed one (a rank takes its OWN slot's value only).
+    std::unique_ptr<std::atomic<ncclComm_t>[]> comms;
+    int n_comms = 0;
     std::vector<float*> host_grads; // replicated + share-gpu: pinned copies of the ranks' partial gradients; [0] receives the sum
     // slab ownership
     std::vector<HaloRank> halo;
@@ -204,8 +238,20 @@ struct s2d_multi {
     // A receiver may call hipStreamWaitEvent on r's event of exchange k only once r has recorded it -- the one thing the
     // rank threads tell each other per iteration, pairwise and without sleeping (no barrier: the streams order the rest)
     std::unique_ptr<std::atomic<unsigned>[]> sent_seq;
-    std::atomic<bool> comms_aborted{false};
-    bool dead = false;              // a collective was aborted: the communicators are gone, the handle must be re-created
+    std::atomic<bool> comms_aborted{false};   // a stop was published during the current command: no rank starts a collective any more
+    std::atomic<bool> collective_lost{false}; // some communicator really was aborted
+    std::atomic<bool> timed_out{false};       // some wait ran out: the ranks no longer agree on where the run stands
+    bool dead = false;              // a collective was aborted or a rank stopped answering: the handle must be re-created
+    bool stuck = false;             // ... and some worker never came back: its thread and context are abandoned, not freed
+    // A rank that stops answering (a device wait that never ends, a thread that died) must not hang the caller: every
+    // wait of one rank for another, and for its own stream, gives up after this long without progress (milliseconds;
+    // S2D_MULTI_STALL_TIMEOUT_MS or s2d_multi_set_stall_timeout; 0 = wait for ever, the behaviour up to round 3)
+    std::atomic<int> stall_ms{30000};
+    std::unique_ptr<Progress[]> progress;
+    std::vector<hipEvent_t> ev_prog;      // [rank * 3 + which], see prog_event()
+    std::vector<char> rank_done;          // guarded by m
+    // test hook (include/splat2d_test.h): rank `stall_rank` stops before its exchange of iteration `stall_iter`
+    int stall_rank = -1, stall_iter = -1, stall_for_ms = 0;
     // command hand-out
     std::vector<std::thread> workers;
     std::mutex m;
@@ -259,12 +305,115 @@ void slab_rows(int height, int rank, int world, int* r0, int* r1)
     if (*r1 > height) *r1 = height;
 }
 
-// Barrier of the rank threads; false once some rank has failed (the caller stops).
+inline void at_phase(s2d_multi* m, int rank, int phase, int iteration)
+{
+    Progress& P = m->progress[(size_t)rank];
+    P.phase.store(phase, std::memory_order_relaxed);
+    P.iteration.store(iteration, std::memory_order_relaxed);
+    P.ticks.fetch_add(1, std::memory_order_release);
+}
+
+// This rank's communicator, taken out of its slot and aborted (RCCL then ends the kernels of this rank that wait for a
+// peer which will never arrive).  Whoever empties the slot owns the communicator: no second abort, no destroy afterwards.
+void abort_own_collective(s2d_multi* m, int rank)
+{
+    if (m->scheme != SCHEME_REPLICATED || m->share_gpu || rank >= m->n_comms) return;
+    const ncclComm_t c = m->comms[(size_t)rank].exchange(nullptr);
+    if (!c) return;
+    m->collective_lost.store(true);
+    if (m->rccl.CommAbort) (void)m->rccl.CommAbort(c);
+}
+
+// A rank has failed (or stopped answering): publish the stop FIRST -- no rank may start another collective, every rank
+// thread leaves its waits -- and only then give up this rank's own communicator.  The other ranks abort theirs when they
+// notice (stopped()): a communicator is never freed under the thread that may be submitting to it.
+void stop_everybody(s2d_multi* m, int rank)
+{
+    m->comms_aborted.store(true);
+    m->barrier.abort();
+    abort_own_collective(m, rank);
+}
+
+// Called by a rank thread inside its waits: has somebody failed?  Then this rank gives up its communicator too.
+inline bool stopped(s2d_multi* m, int rank)
+{
+    if (!m->barrier.broken.load(std::memory_order_acquire)) return false;
+    abort_own_collective(m, rank);
+    return true;
+}
+
+// Barrier of the rank threads; false once some rank has failed (the caller stops) or did not arrive in time.
 bool meet(s2d_multi* m)
 {
     m->barrier.wait();
     return !m->barrier.broken;
 }
+
+// meet() for a rank: S2D_OK, kStopped (somebody else failed), or S2D_E_STATE when the wait itself ran out -- some rank
+// never arrived; the first rank to notice reports it.
+int meet_rank(s2d_multi* m, int r, const char* where)
+{
+    m->barrier.wait();
+    if (!m->barrier.broken) return S2D_OK;
+    if (m->barrier.timed_out.exchange(false)) {
+        std::string missing;
+        for (int q = 0; q < m->world; q++) {
+            const Progress& P = m->progress[(size_t)q];
+            char one[96];
+            snprintf(one, sizeof(one), "%srank %d: %s, iteration %d", missing.empty() ? "" : "; ", q, phase_name(P.phase.load()), P.iteration.load());
+            missing += one;
+        }
+        m->timed_out.store(true);
+        stop_everybody(m, r);
+        return rank_fail(m, r, S2D_E_STATE, "a rank did not reach the rendezvous of the %s within %d ms (%s)", where,
+                         m->barrier.timeout_ms.load(), missing.c_str());
+    }
+    (void)stopped(m, r);
+    return kStopped;
+}
+
+// Wait, with a bound, until everything queued on rank r's stream so far has run.  hipStreamSynchronize would wait for
+// ever behind a kernel that never ends (a collective whose peer is gone, a device that stopped); an event and a poll
+// let the thread notice a stop published by another rank, abort its own collective, and give up with a report.
+int wait_event(s2d_multi* m, int r, hipEvent_t ev, const char* what)
+{
+    const int limit = m->stall_ms.load();
+    const auto t0 = std::chrono::steady_clock::now();
+    bool aborted = false;
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return aborted ? kStopped : S2D_OK;
+        if (e != hipErrorNotReady) return rank_fail(m, r, S2D_E_HIP, "hipEventQuery while %s: %s", what, hipGetErrorString(e));
+        if (!aborted && stopped(m, r)) aborted = true; // keep polling: with its collective aborted the stream drains
+        const long long waited = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (limit > 0 && waited > (aborted ? 2LL * limit : (long long)limit)) {
+            if (aborted) return kStopped; // somebody else already reports; this stream is left as it is
+            const Progress& P = m->progress[(size_t)r];
+            m->timed_out.store(true);
+            stop_everybody(m, r);
+            return rank_fail(m, r, S2D_E_STATE, "rank %d (device %d): the device did not finish the work queued on its stream within %d ms "
+                                                "while %s (iteration %d)", r, m->devices[(size_t)r], limit, what, P.iteration.load());
+        }
+        if (spins < 2000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 200));
+    }
+}
+
+// Three events per rank: [0], [1] mark every 64th iteration of a step (rank_step waits for the one before last, so a
+// wait never covers more than 128 iterations of device work and never leaves the device idle); [2] is for one-off drains.
+int drain(s2d_multi* m, int r, hipEvent_t ev, hipStream_t stream, const char* what)
+{
+    if (ev == nullptr) { // before the events exist (creation failed half-way): the plain wait
+        MHIP(m, r, hipStreamSynchronize(stream));
+        return S2D_OK;
+    }
+    MHIP(m, r, hipEventRecord(ev, stream));
+    return wait_event(m, r, ev, what);
+}
+
+inline hipEvent_t prog_event(s2d_multi* m, int r, int which) { return m->ev_prog.empty() ? nullptr : m->ev_prog[(size_t)r * 3 + (size_t)which]; }
+inline int drain_now(s2d_multi* m, int r, const char* what) { return drain(m, r, prog_event(m, r, 2), (hipStream_t)s2d_stream(m->ctx[(size_t)r]), what); }
+
 
 // Device-to-device copy between two ranks' buffers, queued on `stream` (the receiver's): over xGMI between two GPUs,
 // an ordinary device copy when the ranks share one.
@@ -280,22 +429,21 @@ hipError_t rank_copy(s2d_multi* m, void* dst, int dst_rank, const void* src, int
 // replicated state: the sum RCCL would form, through host memory (S2D_MULTI_SHARE_GPU): every rank copies its partial
 // gradients out, rank 0 adds them in rank order, every rank copies the sum back in.
 // ---------------------------------------------------------------------------------------------------------------------
-bool staged_all_reduce(s2d_multi* m, int rank, float* grads, size_t count, hipStream_t stream)
+int staged_all_reduce(s2d_multi* m, int rank, float* grads, size_t count, hipStream_t stream)
 {
-    bool ok = hipMemcpyAsync(m->host_grads[(size_t)rank], grads, count * sizeof(float), hipMemcpyDeviceToHost, stream) == hipSuccess &&
-              hipStreamSynchronize(stream) == hipSuccess;
-    m->barrier.wait();
+    MHIP(m, rank, hipMemcpyAsync(m->host_grads[(size_t)rank], grads, count * sizeof(float), hipMemcpyDeviceToHost, stream));
+    if (int rc = drain_now(m, rank, "copying its gradients out for the staged all-reduce")) return rc;
+    if (int rc = meet_rank(m, rank, "staged all-reduce (partials out)")) return rc;
     if (rank == 0)
         for (int q = 1; q < m->world; q++) {
             const float* src = m->host_grads[(size_t)q];
             float* dst = m->host_grads[0];
             for (size_t k = 0; k < count; k++) dst[k] += src[k];
         }
-    m->barrier.wait();
-    ok = ok && hipMemcpyAsync(grads, m->host_grads[0], count * sizeof(float), hipMemcpyHostToDevice, stream) == hipSuccess &&
-         hipStreamSynchronize(stream) == hipSuccess;
-    m->barrier.wait(); // nobody overwrites its host copy before everybody has read the sum
-    return ok;
+    if (int rc = meet_rank(m, rank, "staged all-reduce (sum formed)")) return rc;
+    MHIP(m, rank, hipMemcpyAsync(grads, m->host_grads[0], count * sizeof(float), hipMemcpyHostToDevice, stream));
+    if (int rc = drain_now(m, rank, "copying the summed gradients in")) return rc;
+    return meet_rank(m, rank, "staged all-reduce (sum read)"); // nobody overwrites its host copy before everybody has read the sum
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -355,8 +503,7 @@ int plan(s2d_multi* m, int r)
         MHIP(m, r, hipMemcpyAsync(H.d_rows.p, rows.data(), rows.size() * 4, hipMemcpyHostToDevice, stream));
         MHIP(m, r, hipMemcpyAsync(H.d_src.p, src.data(), src.size() * 4, hipMemcpyHostToDevice, stream));
     }
-    MHIP(m, r, hipStreamSynchronize(stream)); // the host vectors go away
-    return S2D_OK;
+    return drain_now(m, r, "uploading its exchange plan"); // the host vectors go away
 }
 
 // After the plans of all ranks are in (behind a barrier): does anybody swap anything, and do the two sides of every
@@ -395,7 +542,7 @@ int hold_fresh(s2d_multi* m, int r)
     H.out_off.assign((size_t)m->world, 0);
     if (int rc = s2d_halo_masks(c, m->world, m->bounds.data(), m->margin, H.d_mask.p)) return rc;
     MHIP(m, r, hipMemcpyAsync(H.fresh.data(), H.d_mask.p, n * 4, hipMemcpyDeviceToHost, stream));
-    MHIP(m, r, hipStreamSynchronize(stream));
+    if (int rc = drain_now(m, r, "reading the hold-set words")) return rc;
     for (size_t i = 0; i < n; i++)
         if ((H.fresh[i] >> r) & 1u) {
             H.mask[i] = H.fresh[i];
@@ -404,7 +551,7 @@ int hold_fresh(s2d_multi* m, int r)
     MHIP(m, r, hipMemcpyAsync(H.d_mask.p, H.mask.data(), n * 4, hipMemcpyHostToDevice, stream));
     if (int rc = s2d_halo_commit(c, H.d_mask.p, r, 1)) return rc;
     if (int rc = plan(m, r)) return rc;
-    if (!meet(m)) return kStopped;
+    if (int rc = meet_rank(m, r, "hold sets")) return rc;
     return settle_plans(m, r);
 }
 
@@ -419,10 +566,11 @@ int refresh(s2d_multi* m, int r)
     const int world = m->world;
     const size_t n = (size_t)m->n;
     const uint32_t me = 1u << r;
+    if (int rc = drain_now(m, r, "finishing the iterations before a hold-set refresh")) return rc; // up to `interval` iterations of device work
     if (int rc = s2d_synchronize(c)) return rc; // the finite guard; and every copy this rank queued has landed
     if (int rc = s2d_halo_masks(c, world, m->bounds.data(), m->margin, H.d_mask.p)) return rc;
     MHIP(m, r, hipMemcpyAsync(H.fresh.data(), H.d_mask.p, n * 4, hipMemcpyDeviceToHost, stream));
-    MHIP(m, r, hipStreamSynchronize(stream));
+    if (int rc = drain_now(m, r, "reading the hold-set words")) return rc;
     for (int q = 0; q < world; q++) {
         H.out_ids[(size_t)q].clear();
         H.out_mask[(size_t)q].clear();
@@ -461,9 +609,9 @@ int refresh(s2d_multi* m, int r)
         MHIP(m, r, hipMemcpyAsync(H.d_pay_ids.p, pay_ids.data(), (size_t)k_out * 4, hipMemcpyHostToDevice, stream));
         if (int rc = s2d_rows_gather(c, S2D_ROWS_SPLATS, H.d_pay_ids.p, k_out, H.d_pay_sp.p)) return rc;
         if (int rc = s2d_rows_gather(c, S2D_ROWS_ADAM, H.d_pay_ids.p, k_out, H.d_pay_ad.p)) return rc;
-        MHIP(m, r, hipStreamSynchronize(stream));
+        if (int rc = drain_now(m, r, "gathering the state rows it hands over")) return rc;
     }
-    if (!meet(m)) return kStopped; // every rank's outgoing rows are in place, every stream is idle
+    if (int rc = meet_rank(m, r, "hold-set refresh (state rows out)")) return rc; // every rank's outgoing rows are in place, every stream is idle
     // incoming state rows, in sender order
     std::vector<int32_t> in_ids;
     std::vector<uint32_t> in_mask;
@@ -492,7 +640,7 @@ int refresh(s2d_multi* m, int r)
             }
         std::vector<float> sp((size_t)k_in * 9);
         MHIP(m, r, hipMemcpyAsync(sp.data(), H.d_in_sp.p, sp.size() * sizeof(float), hipMemcpyDeviceToHost, stream));
-        MHIP(m, r, hipStreamSynchronize(stream));
+        if (int rc = drain_now(m, r, "fetching the state rows handed to it")) return rc;
         // a splat that arrives already touching this rank's rows was rasterised here without being listed: the margin
         // did not outlast the interval
         const float r0 = (float)m->bounds[(size_t)r], r1 = (float)m->bounds[(size_t)r + 1];
@@ -503,7 +651,7 @@ int refresh(s2d_multi* m, int r)
         }
     }
     if (late) m->late.fetch_add(late);
-    if (!meet(m)) return kStopped; // everybody has fetched its rows and reported late arrivals
+    if (int rc = meet_rank(m, r, "hold-set refresh (state rows in)")) return rc; // everybody has fetched its rows and reported late arrivals
     if (m->late.load() > 0)        // fatal on every rank alike
         return rank_fail(m, r, S2D_E_STATE, "slab ownership: %d splat(s) reached the rows of a rank before their state was handed "
                                             "over (%d on rank %d): the margin of %.1f rows did not outlast %d iterations",
@@ -520,20 +668,40 @@ int refresh(s2d_multi* m, int r)
     MHIP(m, r, hipMemcpyAsync(H.d_mask.p, H.mask.data(), n * 4, hipMemcpyHostToDevice, stream));
     if (int rc = s2d_halo_commit(c, H.d_mask.p, r, k_in > 0)) return rc; // departures alone leave the tile lists valid
     if (int rc = plan(m, r)) return rc;
-    if (!meet(m)) return kStopped; // plans are in; the outgoing buffers may be re-used
+    if (int rc = meet_rank(m, r, "hold-set refresh (plans)")) return rc; // plans are in; the outgoing buffers may be re-used
     return settle_plans(m, r);
 }
 
-// Has rank p's thread issued (gathered + recorded the event of) exchange number `seq`?  Spins without sleeping: the
-// threads queue an iteration in tens of microseconds and run at the same pace, so the wait is short; a failed rank ends it.
-bool wait_issued(s2d_multi* m, int p, unsigned seq)
+// Has rank p's thread issued (gathered + recorded the event of) exchange number `seq`?  Spins without sleeping at first:
+// the threads queue an iteration in tens of microseconds and run at the same pace, so the wait is short.  A failed rank
+// ends it (kStopped); a rank that does not answer within the stall limit ends it too, with a report that names it
+// (S2D_E_STATE): the reference's only failure policy is abort() (main.cpp:752-785), the boundary turns "a rank stopped
+// answering" into a status like the rest.
+int wait_issued(s2d_multi* m, int r, int p, unsigned seq)
 {
     const std::atomic<unsigned>& a = m->sent_seq[(size_t)p];
+    const int limit = m->stall_ms.load();
+    std::chrono::steady_clock::time_point t0;
     for (unsigned spins = 0; a.load(std::memory_order_acquire) < seq; spins++) {
-        if (m->barrier.broken) return false;
-        if (spins > 64) std::this_thread::yield();
+        if (stopped(m, r)) return kStopped;
+        if (spins <= 64) continue;
+        if (spins == 65) t0 = std::chrono::steady_clock::now();
+        if (spins < 4096) {
+            std::this_thread::yield();
+            continue;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(50));
+        if (limit > 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(limit)) {
+            const Progress& P = m->progress[(size_t)p];
+            const int it = m->progress[(size_t)r].iteration.load();
+            m->timed_out.store(true);
+            stop_everybody(m, r);
+            return rank_fail(m, r, S2D_E_STATE, "rank %d (device %d) stopped answering: it has not issued gradient exchange %u (iteration %d) "
+                                                "%d ms after rank %d asked for it; it was last seen at '%s', iteration %d", p,
+                             m->devices[(size_t)p], seq, it, limit, r, phase_name(P.phase.load()), P.iteration.load());
+        }
     }
-    return true;
+    return S2D_OK;
 }
 
 // The iteration's exchange: the partial gradient rows of splats this rank shares go to their other holders, theirs
@@ -561,7 +729,7 @@ int exchange_grads(s2d_multi* m, int r)
     for (int p = 0; p < m->world; p++) {
         const int cnt = H.splits[(size_t)p];
         if (p == r || cnt == 0) continue;
-        if (!wait_issued(m, p, seq)) return kStopped;
+        if (int rc = wait_issued(m, r, p, seq)) return rc;
         const HaloRank& P = m->halo[(size_t)p];
         MHIP(m, r, hipStreamWaitEvent(stream, P.ev_sent[b], 0));
         MHIP(m, r, rank_copy(m, H.d_recv.p + (size_t)H.offsets[(size_t)p] * 9, r, P.d_send[b].p + (size_t)P.offsets[(size_t)r] * 9, p,
@@ -572,20 +740,13 @@ int exchange_grads(s2d_multi* m, int r)
     return S2D_OK;
 }
 
-// Replicated state over RCCL: a rank that fails before it has queued its share of a collective leaves the others
-// waiting inside theirs for good.  Abort every communicator (RCCL then ends the kernels that wait for the missing
-// rank), once; the handle is dead afterwards -- s2d_multi_destroy and a new s2d_multi_create bring it back.
-void abort_collectives(s2d_multi* m)
-{
-    if (m->scheme != SCHEME_REPLICATED || m->share_gpu || m->comms.empty()) return;
-    if (m->comms_aborted.exchange(true)) return;
-    for (ncclComm_t& c : m->comms) {
-        if (c && m->rccl.CommAbort) (void)m->rccl.CommAbort(c);
-        if (m->rccl.CommAbort) c = nullptr; // aborted communicators are freed: nothing left to destroy
-    }
-}
-
 // One rank's share of s2d_multi_step: `iters` frames of main.cpp:334 on its rows.
+//
+// Replicated state over RCCL: a rank that fails before it has queued its share of a collective leaves the others waiting
+// inside theirs for good.  The failing rank publishes the stop and aborts ITS communicator (stop_everybody); every other
+// rank aborts its own as soon as one of its bounded waits sees the stop (RCCL then ends the kernels that wait for the
+// missing rank), and no rank submits a collective once comms_aborted is set.  The handle is dead afterwards --
+// s2d_multi_destroy and a new s2d_multi_create bring it back.
 int rank_step(s2d_multi* m, int rank)
 {
     s2d_ctx* c = m->ctx[(size_t)rank];
@@ -594,31 +755,66 @@ int rank_step(s2d_multi* m, int rank)
     hipStream_t stream = (hipStream_t)s2d_stream(c);
     const size_t count = (size_t)m->n * 9;
     int rc = S2D_OK;
+    int marks = 0; // progress marks recorded so far in this call
     for (int k = 0; k < m->step_iters && rc == S2D_OK && !m->barrier.broken; k++) {
         const bool last = k + 1 == m->step_iters;
+        const int it = m->step_first_iter + k;
+        at_phase(m, rank, PH_RASTER, it);
         rc = s2d_forward_backward(c, bwd_flags | (last ? 0u : S2D_FB_SKIP_IMAGE));
         if (rc != S2D_OK) break;
+        if (rank == m->stall_rank && it == m->stall_iter) { // test hook: this rank's thread stops answering here
+            const auto t0 = std::chrono::steady_clock::now();
+            while (!m->barrier.broken && (m->stall_for_ms < 0 || std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(m->stall_for_ms)))
+                std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
         // the only exchange of the iteration
         if (m->scheme == SCHEME_OWNERSHIP) {
+            at_phase(m, rank, PH_EXCHANGE, it);
             rc = exchange_grads(m, rank);
         } else if (m->scheme == SCHEME_REPLICATED) { // (a handle on one device goes through RCCL too: same code whatever N)
+            at_phase(m, rank, PH_ALLREDUCE, it);
             if (m->share_gpu) {
-                if (m->world > 1 && !staged_all_reduce(m, rank, grads, count, stream)) rc = S2D_E_HIP;
-            } else if (m->rccl.AllReduce(grads, grads, count, ncclFloat, ncclSum, m->comms[(size_t)rank], stream) != ncclSuccess) {
-                rc = rank_fail(m, rank, S2D_E_HIP, "ncclAllReduce failed");
+                if (m->world > 1) rc = staged_all_reduce(m, rank, grads, count, stream);
+            } else {
+                // this rank's own slot: nobody frees what it holds while comms_aborted is clear, and once it is set no
+                // collective is started any more
+                const ncclComm_t comm = m->comms_aborted.load() ? nullptr : m->comms[(size_t)rank].load();
+                if (!comm) rc = stopped(m, rank) ? kStopped : rank_fail(m, rank, S2D_E_STATE, "no communicator (aborted)");
+                else if (m->rccl.AllReduce(grads, grads, count, ncclFloat, ncclSum, comm, stream) != ncclSuccess)
+                    rc = rank_fail(m, rank, S2D_E_HIP, "ncclAllReduce failed");
             }
         }
-        if (rc == S2D_OK) rc = s2d_adam_step(c, m->step_flags);
-        if (rc == S2D_OK && m->scheme == SCHEME_OWNERSHIP && (m->hold_age + k + 1) % m->interval == 0) rc = refresh(m, rank);
+        if (rc == S2D_OK) {
+            at_phase(m, rank, PH_ADAM, it);
+            rc = s2d_adam_step(c, m->step_flags);
+        }
+        if (rc == S2D_OK && m->scheme == SCHEME_OWNERSHIP && (m->hold_age + k + 1) % m->interval == 0) {
+            at_phase(m, rank, PH_REFRESH, it);
+            rc = refresh(m, rank);
+        } else if (rc == S2D_OK && m->scheme != SCHEME_OWNERSHIP && (k + 1) % 64 == 0 && !last && prog_event(m, rank, 0)) {
+            // no refresh paces these schemes: mark every 64th iteration on the stream and wait for the mark BEFORE the one
+            // just recorded, so the host never runs more than 128 iterations ahead of the device, the device never waits
+            // for the host, and a device that stopped is noticed within the stall limit
+            MHIP(m, rank, hipEventRecord(prog_event(m, rank, marks & 1), stream));
+            marks++;
+            if (marks >= 2) {
+                at_phase(m, rank, PH_DRAIN, it);
+                rc = wait_event(m, rank, prog_event(m, rank, marks & 1), "running a batch of 64 iterations");
+            }
+        }
     }
     std::vector<double>& mine = m->sqerr[(size_t)rank];
     mine.assign((size_t)m->step_iters, 0.0);
     // A rank that failed on the way (not the finite guard below, which every replica sees alike and which leaves every
     // collective queued): the others may already sit in an all-reduce that will never get this rank's share
-    if (rc != S2D_OK && rc != kStopped) abort_collectives(m);
+    if (rc != S2D_OK && rc != kStopped) stop_everybody(m, rank);
+    if (rc == S2D_OK) {
+        at_phase(m, rank, PH_DRAIN, m->step_first_iter + m->step_iters);
+        rc = drain_now(m, rank, "finishing the iterations of this call");
+    }
     if (rc == S2D_OK && m->step_iters > 0) rc = s2d_get_sqerr_trace(c, m->step_first_iter, m->step_iters, mine.data());
     if (rc == S2D_OK) rc = s2d_synchronize(c); // the finite guard, main.cpp:752-785
-    if (rc != S2D_OK) m->barrier.abort();      // the other ranks stop at their next barrier instead of waiting
+    if (rc != S2D_OK) m->barrier.abort();      // the other ranks stop at their next wait instead of sitting in it
     return rc;
 }
 
@@ -641,41 +837,108 @@ void worker_main(s2d_multi* m, int rank)
         int rc = S2D_OK;
         if (cmd == CMD_STEP) rc = rank_step(m, rank);
         if (cmd == CMD_HOLD) {
+            at_phase(m, rank, PH_HOLD, 0);
             rc = hold_fresh(m, rank);
             if (rc != S2D_OK) m->barrier.abort();
         }
         if (cmd == CMD_FORWARD) { // the rank's rows of image0 from the current parameters (it holds every splat that reaches them)
+            at_phase(m, rank, PH_FORWARD, 0);
             rc = s2d_forward(m->ctx[(size_t)rank]);
+            if (rc == S2D_OK) rc = drain_now(m, rank, "rendering its rows");
             if (rc == S2D_OK) rc = s2d_synchronize(m->ctx[(size_t)rank]);
         }
+        at_phase(m, rank, PH_DONE, 0);
         {
             std::lock_guard<std::mutex> lk(m->m);
             m->rank_rc[(size_t)rank] = rc;
+            m->rank_done[(size_t)rank] = 1;
             m->done_count++;
         }
         m->cv_done.notify_one();
     }
 }
 
-// Hand `cmd` to every worker and wait for all of them.
+// Hand `cmd` to every worker and wait for all of them -- with a watchdog: the ranks' own waits are bounded (wait_issued,
+// wait_event, the barrier), but a rank can also sit inside a runtime call this file cannot bound (a synchronous copy in
+// a context's list rebuild behind a kernel that never ends, a collective's submission).  When NO rank has changed phase
+// for twice the stall limit the caller stops everybody, gives the ranks one more limit to come back, and otherwise
+// returns without them: the handle is then `stuck` -- its abandoned threads and contexts are never freed (a thread
+// inside a runtime call cannot be cancelled) -- and every later call is refused.
 void run_command(s2d_multi* m, int cmd)
 {
     for (std::string& s : m->rank_msg) s.clear();
     m->late = 0;
+    m->comms_aborted.store(false); // (a dead handle never gets here)
     m->barrier.reset();
+    m->barrier.timeout_ms = m->stall_ms.load() > 0 ? 2 * m->stall_ms.load() : 0;
     {
         std::lock_guard<std::mutex> lk(m->m);
         m->cmd = cmd;
         m->cmd_seq++;
         m->done_count = 0;
+        std::fill(m->rank_done.begin(), m->rank_done.end(), 0);
     }
     m->cv_cmd.notify_all();
     std::unique_lock<std::mutex> lk(m->m);
-    m->cv_done.wait(lk, [&] { return m->done_count == m->world; });
+    const auto all_done = [&] { return m->done_count == m->world; };
+    uint64_t seen = 0;
+    auto moved = std::chrono::steady_clock::now();
+    bool stopping = false;
+    for (;;) {
+        const int limit = m->stall_ms.load();
+        if (limit <= 0) {
+            m->cv_done.wait(lk, all_done);
+            return;
+        }
+        if (m->cv_done.wait_for(lk, std::chrono::milliseconds(std::max(10, std::min(250, limit / 4))), all_done)) return;
+        uint64_t ticks = (uint64_t)m->done_count;
+        for (int r = 0; r < m->world; r++) ticks += m->progress[(size_t)r].ticks.load(std::memory_order_acquire);
+        const auto now = std::chrono::steady_clock::now();
+        if (ticks != seen) {
+            seen = ticks;
+            moved = now;
+            continue;
+        }
+        const long long quiet = std::chrono::duration_cast<std::chrono::milliseconds>(now - moved).count();
+        if (!stopping && quiet > 2LL * limit + 1000) {
+            stopping = true;
+            moved = now;
+            m->timed_out.store(true);
+            m->comms_aborted.store(true);
+            m->barrier.abort();
+            // last resort for a rank that sits inside a collective's submission or behind its kernel and cannot look up:
+            // take its communicator out of its slot and abort it from here
+            if (m->scheme == SCHEME_REPLICATED && !m->share_gpu)
+                for (int r = 0; r < m->n_comms; r++)
+                    if (!m->rank_done[(size_t)r]) {
+                        const ncclComm_t c = m->comms[(size_t)r].exchange(nullptr);
+                        if (c) m->collective_lost.store(true);
+                        if (c && m->rccl.CommAbort) (void)m->rccl.CommAbort(c);
+                    }
+        } else if (stopping && quiet > (long long)limit + 1000) {
+            std::string who;
+            for (int r = 0; r < m->world; r++)
+                if (!m->rank_done[(size_t)r]) {
+                    const Progress& P = m->progress[(size_t)r];
+                    char one[128];
+                    snprintf(one, sizeof(one), "%srank %d (device %d) at '%s', iteration %d", who.empty() ? "" : "; ", r, m->devices[(size_t)r],
+                             phase_name(P.phase.load()), P.iteration.load());
+                    who += one;
+                    m->rank_rc[(size_t)r] = S2D_E_STATE;
+                    m->rank_msg[(size_t)r] = "did not come back";
+                }
+            m->stuck = true;
+            m->dead = true;
+            snprintf(m->err, sizeof(m->err), "no rank made progress for %d ms and the stop was not answered: %s; the handle is abandoned "
+                                             "(its threads and device memory are not freed)", 3 * limit + 2000, who.c_str());
+            return;
+        }
+    }
 }
 
 int first_failure(s2d_multi* m, const char* what)
 {
+    if (m->stuck) return S2D_E_STATE; // run_command wrote the report
     for (int r = 0; r < m->world; r++) {
         const int rc = m->rank_rc[(size_t)r];
         if (rc != S2D_OK && rc != kStopped)
@@ -708,8 +971,10 @@ struct DeviceGuard {
 
 int refuse_dead(s2d_multi* m)
 {
-    return mfail(m, S2D_E_STATE, "a collective of this handle was aborted after a rank failed: its communicators are gone; "
-                                 "s2d_multi_destroy it and create a new one");
+    if (m->stuck) return S2D_E_STATE; // keeps the watchdog's report
+    return mfail(m, S2D_E_STATE, "%s; s2d_multi_destroy this handle and create a new one",
+                 m->collective_lost.load() ? "a collective of this handle was aborted after a rank failed: its communicators are gone"
+                                           : "a rank of this handle stopped answering and the ranks no longer agree on where the run stands");
 }
 
 inline bool lowest_holder(uint32_t mask, int r) { return mask != 0u && (mask & (0u - mask)) == (1u << r); }
@@ -761,6 +1026,9 @@ int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_de
     m->barrier.n = m->world;
     m->sent_seq.reset(new std::atomic<unsigned>[(size_t)m->world]);
     for (int r = 0; r < m->world; r++) m->sent_seq[(size_t)r].store(0u);
+    m->progress.reset(new Progress[(size_t)m->world]);
+    m->rank_done.assign((size_t)m->world, 0);
+    if (const char* e = getenv("S2D_MULTI_STALL_TIMEOUT_MS")) m->stall_ms = std::max(0, atoi(e));
     m->bounds.resize((size_t)m->world + 1);
     for (int r = 0; r < m->world; r++) {
         s2d_config c = *cfg;
@@ -782,10 +1050,13 @@ int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_de
     if (m->scheme == SCHEME_REPLICATED && !m->share_gpu) {
         std::string why;
         if (!load_rccl(&m->rccl, &why)) return mfail(m, S2D_E_HIP, "%s", why.c_str());
-        m->comms.assign((size_t)m->world, nullptr);
-        const ncclResult_t nrc = m->rccl.CommInitAll(m->comms.data(), m->world, m->devices.data());
-        if (nrc != ncclSuccess) {
-            m->comms.clear();
+        std::vector<ncclComm_t> made((size_t)m->world, nullptr);
+        const ncclResult_t nrc = m->rccl.CommInitAll(made.data(), m->world, m->devices.data());
+        if (nrc == ncclSuccess) {
+            m->comms.reset(new std::atomic<ncclComm_t>[(size_t)m->world]);
+            for (int r = 0; r < m->world; r++) m->comms[(size_t)r].store(made[(size_t)r]);
+            m->n_comms = m->world;
+        } else {
             return mfail(m, S2D_E_HIP, "ncclCommInitAll over %d devices: %s (RCCL takes one rank per GPU; S2D_MULTI_SHARE_GPU rehearses "
                                        "on fewer)", m->world, m->rccl.GetErrorString(nrc));
         }
@@ -812,6 +1083,14 @@ int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_de
                 }
             }
     }
+    // the events of the bounded stream waits (three per rank, prog_event())
+    m->ev_prog.assign((size_t)m->world * 3, nullptr);
+    for (int r = 0; r < m->world; r++) {
+        if (hipSetDevice(m->devices[(size_t)r]) != hipSuccess) return mfail(m, S2D_E_HIP, "hipSetDevice(%d)", m->devices[(size_t)r]);
+        for (int k = 0; k < 3; k++)
+            if (hipEventCreateWithFlags(&m->ev_prog[(size_t)r * 3 + (size_t)k], hipEventDisableTiming) != hipSuccess)
+                return mfail(m, S2D_E_HIP, "hipEventCreate on device %d", m->devices[(size_t)r]);
+    }
     for (int r = 0; r < m->world; r++) m->workers.emplace_back(worker_main, m, r);
     return S2D_OK;
 }
@@ -820,6 +1099,12 @@ void s2d_multi_destroy(s2d_multi* m)
 {
     if (!m) return;
     DeviceGuard guard;
+    if (m->stuck) {
+        // some worker sits inside a runtime call that never returned: it cannot be joined, and what it may still touch
+        // -- the handle, its context, its device memory -- cannot be freed under it.  Abandon all of it.
+        for (auto& t : m->workers) t.detach();
+        return;
+    }
     if (!m->workers.empty()) {
         {
             std::lock_guard<std::mutex> lk(m->m);
@@ -829,8 +1114,10 @@ void s2d_multi_destroy(s2d_multi* m)
         m->cv_cmd.notify_all();
         for (auto& t : m->workers) t.join();
     }
-    for (ncclComm_t c : m->comms)
-        if (c) m->rccl.CommDestroy(c);
+    for (int r = 0; r < m->n_comms; r++)
+        if (const ncclComm_t c = m->comms[(size_t)r].exchange(nullptr)) m->rccl.CommDestroy(c);
+    for (size_t k = 0; k < m->ev_prog.size(); k++)
+        if (m->ev_prog[k] && hipSetDevice(m->devices[k / 3]) == hipSuccess) (void)hipEventDestroy(m->ev_prog[k]);
     for (float* p : m->host_grads)
         if (p) (void)hipHostFree(p);
     for (s2d_ctx* c : m->ctx)
@@ -841,6 +1128,46 @@ void s2d_multi_destroy(s2d_multi* m)
 const char* s2d_multi_last_error(const s2d_multi* m) { return m ? m->err : "null handle"; }
 
 int s2d_multi_device_count(const s2d_multi* m) { return m ? m->world : 0; }
+
+int s2d_multi_set_stall_timeout(s2d_multi* m, int32_t milliseconds)
+{
+    if (!m || milliseconds < 0) return S2D_E_INVALID;
+    m->stall_ms = milliseconds;
+    return S2D_OK;
+}
+
+int s2d_multi_device_info(s2d_multi* m, int32_t rank, int32_t* device, int32_t* row_begin, int32_t* row_end, char* pci_bus_id,
+                          int32_t pci_capacity, char* name, int32_t name_capacity)
+{
+    if (!m || rank < 0 || rank >= m->world) return S2D_E_INVALID;
+    const int dev = m->devices[(size_t)rank];
+    if (device) *device = dev;
+    if (row_begin) *row_begin = m->row_begin[(size_t)rank];
+    if (row_end) *row_end = m->row_end[(size_t)rank];
+    if (pci_bus_id && pci_capacity > 0) {
+        pci_bus_id[0] = 0;
+        if (hipDeviceGetPCIBusId(pci_bus_id, pci_capacity, dev) != hipSuccess) {
+            (void)hipGetLastError();
+            pci_bus_id[0] = 0;
+        }
+    }
+    if (name && name_capacity > 0) {
+        hipDeviceProp_t prop;
+        name[0] = 0;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) snprintf(name, (size_t)name_capacity, "%s", prop.name);
+        else (void)hipGetLastError();
+    }
+    return S2D_OK;
+}
+
+int s2d_test_multi_stall(s2d_multi* m, int32_t rank, int32_t iteration, int32_t milliseconds)
+{
+    if (!m) return S2D_E_INVALID;
+    m->stall_rank = rank;
+    m->stall_iter = iteration;
+    m->stall_for_ms = milliseconds;
+    return S2D_OK;
+}
 
 int s2d_multi_exchange_info(s2d_multi* m, int64_t* out4)
 {
@@ -965,7 +1292,7 @@ int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out)
             if (s2d_get_adam(c, nullptr, nullptr, nullptr, &it) == S2D_OK) earliest = std::min(earliest, it);
         }
         if (earliest != INT32_MAX) m->iterations = earliest;
-        if (m->comms_aborted.load()) m->dead = true;
+        if (m->collective_lost.load() || m->timed_out.load()) m->dead = true;
         return rc;
     }
     m->iterations += iters;

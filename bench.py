@@ -92,11 +92,34 @@ def kernel_source_digest():
     return importlib.import_module("2dgaussiansplatting_amd._build").kernel_source_digest()
 
 
-def spawn_ranks(n, argv):
-    """N > 1 without a launcher: start the ranks as a CHILD torch.distributed.run (this process has not touched the
-    GPU and never does), pass its output through, return its exit code."""
+STAGES = ["spawn", "start", "init", "selftest", "warmup", "timed", "psnr", "side-block", "report", "done"]
+
+
+def stage(rank, name):
+    """Stage marker of a rank, on stderr: the parent's watchdog keeps the latest one so that a run that stops says where."""
+    sys.stderr.write("[bench stage] rank %d: %s\n" % (rank, name))   # ONE write: the ranks share the pipe
+    sys.stderr.flush()
+
+
+def watchdog_budget(args):
+    """Wall-clock budget of one attempt of the child job, from the amount of work asked for: import + rendezvous + RCCL
+    set-up (up to ~3 minutes on a fresh box) + the iterations (warm-up, timed block, side block, the run up to iteration
+    200 for the PSNR) at a generous 10 ms each.  184 s for the default --steps 100."""
+    if args.watchdog_seconds > 0:
+        return float(args.watchdog_seconds)
+    return 180.0 + 0.01 * (args.warmup + 2 * args.steps + 200)
+
+
+def run_ranks_once(n, argv, budget_s):
+    """Start the N ranks as a CHILD torch.distributed.run in a process group of its own, relay its output, and stop it
+    when the budget runs out.  This (parent) process never touches the GPU.  Returns a dict: rc (None = killed by the
+    watchdog), json_seen, stage reached (the furthest any rank reported), the last stderr lines, seconds."""
+    import collections
+    import re
+    import signal
     import socket
     import subprocess
+    import threading
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -105,12 +128,89 @@ def spawn_ranks(n, argv):
     env.setdefault("OMP_NUM_THREADS", "1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for line in proc.stdout:   # rank 0's JSON line goes to stdout; library chatter of the ranks to stderr
-        out = sys.stdout if line.lstrip().startswith("{") else sys.stderr
-        out.write(line)
-        out.flush()
-    return proc.wait()
+    t0 = time.perf_counter()
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    state = {"json": False, "stage": "spawn", "per_rank": {}}
+    tail = collections.deque(maxlen=25)
+
+    def pump_out():
+        for line in proc.stdout:   # rank 0's JSON line goes to stdout; anything else the ranks print there, to stderr
+            is_json = line.lstrip().startswith("{")
+            state["json"] = state["json"] or is_json
+            out = sys.stdout if is_json else sys.stderr
+            out.write(line)
+            out.flush()
+
+    def pump_err():
+        for line in proc.stderr:
+            marks = re.findall(r"\[bench stage\] rank (\d+): ([a-z-]+)", line)
+            for r, name in marks:
+                state["per_rank"][int(r)] = name
+                if name in STAGES and STAGES.index(name) > STAGES.index(state["stage"]):
+                    state["stage"] = name
+            if not marks:
+                tail.append(line.rstrip()[-300:])
+            sys.stderr.write(line)
+            sys.stderr.flush()
+
+    pumps = [threading.Thread(target=pump_out, daemon=True), threading.Thread(target=pump_err, daemon=True)]
+    for th in pumps:
+        th.start()
+    rc = None
+    try:
+        rc = proc.wait(timeout=budget_s)
+    except subprocess.TimeoutExpired:
+        # the whole group: torch.distributed.run and every rank under it.  Never restarted in place: a second attempt
+        # (run_ranks) is a FRESH child whose processes have not initialised the GPU yet
+        for sig, grace in ((signal.SIGTERM, 5.0), (signal.SIGKILL, 10.0)):
+            try:
+                os.killpg(proc.pid, sig)
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=grace)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+    for th in pumps:
+        th.join(timeout=5.0)
+    return {"rc": rc, "json_seen": state["json"], "stage": state["stage"], "stage_per_rank": dict(sorted(state["per_rank"].items())),
+            "stderr_tail": list(tail), "seconds": time.perf_counter() - t0}
+
+
+def spawn_ranks(n, argv, args):
+    """N > 1 without a launcher.  Whatever happens the caller gets ONE JSON line on stdout: rank 0's result, or -- when
+    the ranks die, or stop answering (a first-contact RCCL / peer-to-peer stall would otherwise end as a kill at the
+    driver's limit with nothing written) -- an {"error": ...} record that names the stage reached and carries the last
+    stderr lines; exit code non-zero then.  If the exchange scheme was left to the default and the run stopped AFTER the
+    process group had come up, one fresh child is tried with --exchange dense (north_star's all-reduce) before giving up."""
+    budget = watchdog_budget(args)
+    attempts = []
+    t_all = time.perf_counter()
+    res = run_ranks_once(n, argv, budget)
+    attempts.append(res)
+    if res["rc"] == 0 and res["json_seen"]:
+        return 0
+    stalled = res["rc"] is None
+    got_going = STAGES.index(res["stage"]) >= STAGES.index("selftest")
+    left = 540.0 - (time.perf_counter() - t_all)
+    if stalled and got_going and args.exchange is None and not args.launch_selftest and left >= 60.0:
+        print("bench.py: the ranks stopped answering at stage '%s' with the default exchange (halo); one fresh attempt with "
+              "--exchange dense" % res["stage"], file=sys.stderr)
+        res = run_ranks_once(n, argv + ["--exchange", "dense"], min(budget, left))
+        attempts.append(res)
+        if res["rc"] == 0 and res["json_seen"]:
+            return 0
+    if not res["json_seen"]:
+        why = ("the ranks stopped answering: no result %.0f s after the launch (watchdog budget %.0f s); the process group was killed"
+               % (res["seconds"], budget)) if res["rc"] is None else "the ranks exited with code %s before rank 0 printed a result" % res["rc"]
+        print(json.dumps({"metric": "train iters/sec (fwd+bwd+Adam) + PSNR vs ref; 4K img, 1M splats", "value": None,
+                          "unit": "iterations/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+                          "error": why, "stage": res["stage"], "stage_per_rank": res["stage_per_rank"],
+                          "attempts": [{"exchange": "default" if k == 0 else "dense", "rc": a["rc"], "stage": a["stage"],
+                                        "seconds": round(a["seconds"], 1)} for k, a in enumerate(attempts)],
+                          "stderr_tail": res["stderr_tail"], "watchdog_budget_s": budget}), flush=True)
+    return res["rc"] if res["rc"] not in (None, 0) else 4
 
 
 def main():
@@ -124,11 +224,11 @@ def main():
     ap.add_argument("--rebin-interval", type=int, default=0)
     ap.add_argument("--fp16-images", action="store_true",
                     help="BASELINE configs[4] 'fp16 colour / fp32 grads': framebuffer and target held as 4 x fp16 per pixel")
-    ap.add_argument("--full-gradient", dest="full_gradient", action="store_true", default=None,
-                    help="after the timed block, time the same steps again with dL/d(opacity) accumulated too (main.cpp:703-704; "
-                         "the timed block leaves it out: with optimizeOpacity off, main.cpp:317, Adam never reads it) and report "
-                         "iterations_per_s_full_gradient beside value.  Default: on for one GPU")
-    ap.add_argument("--no-full-gradient", dest="full_gradient", action="store_false")
+    ap.add_argument("--lean-block", dest="lean_block", action="store_true", default=None,
+                    help="after the timed block (whose backward pass accumulates all nine gradients, like main.cpp:595-710), time the "
+                         "same steps again with dL/d(opacity) skipped (what s2d_step does while optimizeOpacity is off, "
+                         "main.cpp:317,735) and report iterations_per_s_lean beside value.  Default: on for one GPU")
+    ap.add_argument("--no-lean-block", dest="lean_block", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--exchange", default=None, choices=["halo", "dense"],
@@ -138,23 +238,33 @@ def main():
                          "it ends the run with exit code 3 instead")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only "
                     "to rehearse the multi-process path with several ranks sharing one GPU)")
+    ap.add_argument("--watchdog-seconds", type=float, default=0.0,
+                    help="N > 1 started from the plain command: wall-clock budget of the child job before the parent stops it and "
+                         "prints an error record (0 = derived from --steps: 180 s + 10 ms per iteration)")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="only check the multi-process launch path: the ranks rendezvous, all-reduce their rank numbers "
                          "and rank 0 prints one JSON line; needs no GPU (tests/test_distributed_cpu.py)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:], args))
 
     if args.launch_selftest:
         import torch
         import torch.distributed as dist_mod
+        import datetime
         world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+        stage(rank, "start")
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist_mod.init_process_group(backend="gloo")
+            dist_mod.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
+        stage(rank, "init")
+        if os.environ.get("S2D_BENCH_SELFTEST_HANG_RANK") == str(rank):
+            while True:            # a rank that stops answering after the rendezvous (tests/test_distributed_cpu.py)
+                time.sleep(3600)
         v = torch.tensor([rank + 1], dtype=torch.int64)
         if world > 1:
+            stage(rank, "selftest")
             dist_mod.all_reduce(v)
             dist_mod.barrier()
         if os.environ.get("S2D_BENCH_SELFTEST_FAIL_RANK") == str(rank):
@@ -170,9 +280,11 @@ def main():
     S2D = importlib.import_module("2dgaussiansplatting_amd")
     D = importlib.import_module("2dgaussiansplatting_amd.distributed")
 
+    import datetime
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    stage(rank, "start")
     if world != args.gpus:
         args.gpus = world  # the launcher's world size wins
     if not torch.cuda.is_available():
@@ -189,10 +301,23 @@ def main():
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # 120 s, not torch's 10 minutes (longer than the driver's own limit): a rendezvous or a collective that a peer
+        # never joins ends this rank with an error the parent's record can quote
+        tmo = datetime.timedelta(seconds=120)
         if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device), timeout=tmo)
         else:
-            dist.init_process_group(backend=args.backend)
+            dist.init_process_group(backend=args.backend, timeout=tmo)
+    stage(rank, "init")
+    # which physical device this rank runs on: the record must PROVE that N distinct GPUs took part
+    props = torch.cuda.get_device_properties(device)
+    me = {"rank": rank, "device": device, "pid": os.getpid(),
+          "pci_bus_id": "%04x:%02x:%02x.0" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0), getattr(props, "pci_device_id", 0)),
+          "uuid": str(getattr(props, "uuid", "")), "name": props.name, "arch": getattr(props, "gcnArchName", "")}
+    ranks_info = [me]
+    if dist is not None:
+        ranks_info = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks_info, me)
 
     W, H, n = args.width, args.height, args.splats
     r0, r1 = D.slab_rows(H, rank, world)
@@ -205,12 +330,15 @@ def main():
     t = S2D.Trainer(W, H, n, device=device, row_begin=r0, row_end=r1,
                     rebin_interval=args.rebin_interval, fp16_images=args.fp16_images, stream=stream.cuda_stream)
     t.bind_grads(grads.data_ptr())
-    t.lean_backward = True  # optimizeOpacity is off (main.cpp:317): Adam never reads dSplats.opacity (main.cpp:735)
+    # `value` is the reference's whole iteration: all NINE gradients are accumulated, dL/d(opacity) included (main.cpp:703-704
+    # accumulates it every iteration whether or not "Optimize opacity" is on)
+    t.lean_backward = False
     t.set_target_synthetic()
     t.init()
 
     exchange_requested = args.exchange or "halo"
     exchange = exchange_requested if use_dist else "none"
+    stage(rank, "selftest")
     if exchange == "halo" and not D.all_to_all_selftest(dist, "cuda"):
         # the collective pattern slab ownership needs misbehaved on this stack (every rank agreed on that: all-reduce)
         if args.exchange == "halo":
@@ -240,91 +368,81 @@ def main():
         else:  # HIP events around the raster kernel (fused forward + backward), on the stream it is launched on
             step(before_raster=lambda: ev[0].record(stream), after_raster=lambda: ev[1].record(stream))
 
+    def timed_block(steps):
+        """EXACTLY `steps` iterations between barrier + synchronize on both sides; wall clock = max over ranks.  Also, from
+        HIP events on the stream: every step's duration and the raster kernel's launch duration (over the steps that
+        rebuilt no tile list: there the events bracket exactly that kernel + the ~6 us squared-error reduction; on a
+        rebuild step they would also span the void optimistic launch, the rebuild and the relaunch)."""
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]  # step boundaries on the stream
+        reb = []
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            marks[k].record(stream)
+            before = t.rebuild_count()
+            one_step(ev[k])
+            reb.append(t.rebuild_count() != before)  # host-side counter, no synchronisation
+        marks[steps].record(stream)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        t.synchronize()  # raises if a parameter went non-finite
+        reb = np.array(reb, dtype=bool)
+        step_ms = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(steps)], dtype=np.float64)
+        k_ms = np.array([a.elapsed_time(b) for a, b in ev], dtype=np.float64)
+        k_use = k_ms[~reb] if (~reb).any() else k_ms
+        red = torch.tensor([dt, float(k_use.mean()) if steps else 0.0], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(red, op=dist.ReduceOp.MAX)
+        steady = step_ms[~reb] if (~reb).any() else step_ms
+        return {"seconds": float(red[0].item()), "kernel_ms": float(red[1].item()), "step_ms": step_ms, "rebuilds": reb,
+                "steady_ms": float(steady.mean()) if steps else float("nan")}
+
+    stage(rank, "warmup")
     for _ in range(args.warmup):
         one_step()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # step boundaries on the stream
-    rebuilds = []
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        marks[k].record(stream)
-        before = t.rebuild_count()
-        one_step(events[k])
-        rebuilds.append(t.rebuild_count() != before)  # host-side counter, no synchronisation
-    marks[args.steps].record(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    t.synchronize()  # raises if a parameter went non-finite
-    step_ms = np.array([marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps)], dtype=np.float64)
-    rebuilds = np.array(rebuilds, dtype=bool)
+    stage(rank, "timed")
+    blk = timed_block(args.steps)
+    dt, step_ms, rebuilds = blk["seconds"], blk["step_ms"], blk["rebuilds"]
 
-    dt_t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     done = t.stats()["iterations"]
     first = done - args.steps
     # PSNR after a fixed 200 iterations (SURVEY.md section 8d): keep training, untimed, up to iteration 200, and
     # read iteration 199's squared error from the device-side trace ring (it holds the last 65536 iterations)
+    stage(rank, "psnr")
     extra = max(0, 200 - done)
     for _ in range(extra):
         one_step()
     torch.cuda.synchronize()
     psnr_iter = 199 if done + extra - 200 < 60000 else done + extra - 1
     sq200 = torch.from_numpy(t.sqerr_trace(psnr_iter, 1)).cuda()
-    # The whole backward pass of north_star -- dL/dpos, dL/dSigma, dL/dcolour AND dL/dopacity (main.cpp:703-704) -- timed
-    # the same way in a block of its own, outside `value`: the trajectory is the same (Adam reads dSplats.opacity only with
-    # "Optimize opacity" on, main.cpp:735), the raster kernel is its NEED_OP = true instantiation.
-    full = None
-    want_full = args.full_gradient if args.full_gradient is not None else world == 1
-    if want_full and args.steps > 0:
-        t.lean_backward = False
+    # Side block, outside `value`: the same steps with dL/d(opacity) left out (S2D_BWD_SKIP_OPACITY_GRAD: what s2d_step
+    # does by itself while "Optimize opacity" is off, because Adam reads dSplats.opacity only with it on, main.cpp:735) --
+    # same trajectory, the NEED_OP = false instantiation of the raster kernel.
+    lean = None
+    want_lean = args.lean_block if args.lean_block is not None else world == 1
+    if want_lean and args.steps > 0:
+        stage(rank, "side-block")
+        t.lean_backward = True
         for _ in range(min(args.warmup, 5)):
             one_step()
-        fev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-        fmarks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-        freb = []
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        f0 = time.perf_counter()
-        for k in range(args.steps):
-            fmarks[k].record(stream)
-            before = t.rebuild_count()
-            one_step(fev[k])
-            freb.append(t.rebuild_count() != before)
-        fmarks[args.steps].record(stream)
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        fdt = torch.tensor([time.perf_counter() - f0], dtype=torch.float64, device="cuda")
-        if dist is not None:
-            dist.all_reduce(fdt, op=dist.ReduceOp.MAX)
-        t.lean_backward = True
-        freb = np.array(freb, dtype=bool)
-        fstep = np.array([fmarks[k].elapsed_time(fmarks[k + 1]) for k in range(args.steps)], dtype=np.float64)
-        fk = np.array([a.elapsed_time(b) for a, b in fev], dtype=np.float64)
-        fk = fk[~freb] if (~freb).any() else fk
-        fsteady = fstep[~freb] if (~freb).any() else fstep
-        full = {"iterations_per_s": args.steps / float(fdt.item()), "ms_per_step": 1e3 * float(fdt.item()) / args.steps,
-                "iterations_per_s_median": 1e3 / float(np.median(fstep)), "iterations_per_s_steady_state": 1e3 / float(fsteady.mean()),
-                "steps_with_list_rebuild": int(freb.sum()), "kernel_ms": float(fk.mean()), "steps": args.steps}
+        lb = timed_block(args.steps)
+        t.lean_backward = False
+        lean = {"iterations_per_s": args.steps / lb["seconds"], "ms_per_step": 1e3 * lb["seconds"] / args.steps,
+                "iterations_per_s_median": 1e3 / float(np.median(lb["step_ms"])), "iterations_per_s_steady_state": 1e3 / lb["steady_ms"],
+                "steps_with_list_rebuild": int(lb["rebuilds"].sum()), "kernel_ms": lb["kernel_ms"], "steps": args.steps,
+                "backward": "8 of the 9 gradients: dL/dopacity skipped (nothing reads it while optimizeOpacity is off, main.cpp:317,735)"}
+    stage(rank, "report")
     if dist is not None and sq200 is not None:
         D.reduce_sqerr(sq200, dist)
     sq = torch.from_numpy(t.sqerr_trace(first, args.steps)).cuda()
-    # the raster kernel's launch duration: HIP events around its launch on its stream, over the steps that rebuilt no
-    # tile list (there the events bracket exactly that kernel + the ~6 us squared-error reduction; on a rebuild step they
-    # would also span the void optimistic launch, the rebuild and the relaunch)
-    ev_ms = np.array([a.elapsed_time(b) for a, b in events], dtype=np.float64)
-    ev_use = ev_ms[~rebuilds] if (~rebuilds).any() else ev_ms
-    bwd_ms = torch.tensor([float(ev_use.mean()) if args.steps else 0.0], dtype=torch.float64, device="cuda")
+    bwd_ms = blk["kernel_ms"]
     if dist is not None:
-        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
         D.reduce_sqerr(sq, dist)
-        dist.all_reduce(bwd_ms, op=dist.ReduceOp.MAX)
-    dt = float(dt_t.item())
     mse_last = float(sq[-1].item()) / (H * W * 3) if args.steps else float("nan")
     stats = t.stats()
 
@@ -336,11 +454,11 @@ def main():
         # read once per pass (2 x 36 B) and the 9 gradient floats written once (36 B).  (The events also span the
         # ~6 us squared-error reduction queued behind it.)
         bwd_bytes = (24.0 if args.fp16_images else 48.0) * W * (r1 - r0) + 108.0 * n  # fp16 images: 8 B per pixel access
-        bwd_s = float(bwd_ms.item()) * 1e-3
+        bwd_s = bwd_ms * 1e-3
         achieved = bwd_bytes / bwd_s / 1e9 if bwd_s > 0 else 0.0
         # HBM traffic of that kernel from the PMC counters: a RECORDED figure (rocprofv3 cannot run inside this
         # process), valid only for the kernel build and the launch it was measured on -- dropped otherwise
-        traffic, traffic_note = None, "no PMC pass recorded for this build / launch"
+        traffic, traffic_note, pmc = None, "no PMC pass recorded for this build / launch", None
         tp = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tp) and world == 1 and (W, H, n) == (4096, 4096, 1000000) and not args.fp16_images:
             try:
@@ -348,6 +466,7 @@ def main():
                 if tj.get("kernel_source_digest") == kernel_source_digest():
                     traffic = tj.get("dominant_kernel_bytes_per_launch")
                     traffic_note = "recorded: %s" % tj.get("source")
+                    pmc = tj
                 else:
                     traffic_note = "profiles/traffic.json was measured on another kernel build (digest %s): dropped" % tj.get("kernel_source_digest")
             except Exception:
@@ -374,17 +493,21 @@ def main():
             "iterations_per_s_median": (1e3 / float(np.median(step_ms))) if args.steps else None,
             "iterations_per_s_steady_state": (1e3 / float(steady.mean())) if args.steps else None,
             "steps_with_list_rebuild": int(rebuilds.sum()),
-            # the same steps with dL/d(opacity) accumulated as well (the ninth gradient of main.cpp:703-704, which `value`'s
-            # block leaves out because nothing reads it while "Optimize opacity" is off): a block of its own, timed the same way
-            "iterations_per_s_full_gradient": full["iterations_per_s"] if full else None,
-            "full_gradient": full,
-            "backward_in_value": "dL/dpos, dL/dsx, dL/dsy, dL/drot, dL/dcolour (8 of the 9 gradients; dL/dopacity is unused while "
-                                 "optimizeOpacity is off, main.cpp:317,735)",
+            "backward_in_value": "all nine gradients of main.cpp:595-710: dL/dpos, dL/dsx, dL/dsy, dL/drot, dL/dcolour, dL/dopacity",
+            # side block, NOT in `value`: the same steps with dL/d(opacity) skipped (nothing reads it while "Optimize opacity" is
+            # off, main.cpp:317,735; what s2d_step does by itself), timed the same way
+            "iterations_per_s_lean": lean["iterations_per_s"] if lean else None,
+            "lean_backward": lean,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic target ref(x,y)=(x/W,1-x/W,y/H); splats from the reference's init() seeds",
+            # which physical devices took part, gathered from the ranks themselves, and the size of the RCCL / gloo group
+            "ranks": ranks_info,
+            "rccl_world_size": (dist.get_world_size() if dist is not None else 1),
+            "collective_backend": (dist.get_backend() if dist is not None else "none"),
+            "distinct_devices": len({(r or {}).get("uuid") or (r or {}).get("pci_bus_id") for r in ranks_info}),
             "config": {"workload": "%dx%d synthetic RGB, %d Gaussians, %s%s" % (
                            W, H, n, "fp16 colour / fp32 gradients" if args.fp16_images else "fp32",
                            " (BASELINE.json configs[3])" if (W, H, n, args.fp16_images) == (4096, 4096, 1000000, False) else
@@ -408,12 +531,27 @@ def main():
                                {"scheme": "dense" if use_dist else "none", "replica_checksum_checks": getattr(step, "checks", 0)}),
             "pairs_binned_rank0": stats["pairs_binned"],
             "rebins_rank0": stats["rebins"],
-            "roofline": {"bound": "hbm", "kernel": "raster_fused_kernel", "achieved": achieved, "peak": 8000.0,
+            # SURVEY.md section 8d prices this path in HBM bytes, so `roofline` is the HBM one; what actually bounds the kernel is
+            # named beside it (`bound_measured`): it issues vector instructions, the framebuffer traffic is ~6 % of the pipe
+            "roofline": {"bound": "hbm", "kernel": "raster_fused_kernel (all nine gradients: its NEED_OP instantiation)",
+                         "achieved": achieved, "peak": 8000.0,
                          "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel_ms": float(bwd_ms.item()), "algorithmic_bytes_per_launch": bwd_bytes,
+                         "kernel_ms": bwd_ms, "algorithmic_bytes_per_launch": bwd_bytes,
                          "kernel_ms_note": "mean over the launches that did work; rocprofv3's AverageNs for this kernel also counts "
-                                           "one void ~20 us launch per list rebuild (profiles/r03/README.md)"},
+                                           "one void ~20 us launch per list rebuild (profiles/r04/README.md)",
+                         "bound_measured": "valu-issue",
+                         "bound_measured_note": "vector-instruction issue, with the LDS pipe and per-wave latency within ~1.3x of it "
+                                                "(perturbation experiments, profiles/r03/r03_bound_experiments.txt; priced instruction "
+                                                "account ~93 % vector issue, profiles/r03/r03_tile_clock.txt); HBM is the idle resource"},
         }
+        if pmc is not None and pmc.get("SQ_INSTS_VALU_per_launch"):
+            # counter-derived, from the same digest-tied PMC passes as `traffic` (per working launch of the dominant kernel)
+            valu = float(pmc["SQ_INSTS_VALU_per_launch"])
+            out["roofline"]["valu"] = {"wave_instructions_per_launch": valu, "gpu_cycles_per_launch": pmc.get("gpu_cycles_per_launch"),
+                                       "simd_cycles_per_valu_instruction": pmc.get("simd_cycles_per_valu_instruction"),
+                                       "lds_wave_instructions_per_launch": pmc.get("SQ_INSTS_LDS_per_launch"),
+                                       "salu_wave_instructions_per_launch": pmc.get("SQ_INSTS_SALU_per_launch"),
+                                       "source": pmc.get("sq_source")}
         if world == 1:
             # The path has no dense contraction (no MFMA) and the raster kernels are nowhere near bandwidth-bound, so beside the
             # HBM roofline report the useful fp32 VALU rate: active (pixel, splat) pairs per pass, counted by the
@@ -428,6 +566,9 @@ def main():
                 tc.synchronize()
                 cs = tc.stats()
             flops = 30.0 * cs["fwd_active"] + 110.0 * cs["bwd_active"]
+            if "valu" in out["roofline"]:
+                # useful flops / issued lane-operations (64 lanes per wave instruction; no FMA contraction: one flop per lane-op)
+                out["roofline"]["valu"]["useful_lane_fraction"] = flops / (out["roofline"]["valu"]["wave_instructions_per_launch"] * 64.0)
             out["compute"] = {"unit": "TFLOP/s", "achieved": flops * its / 1e12, "peak": 157.3,
                               "frac": flops * its / 1e12 / 157.3, "active_pairs_per_pass": cs["bwd_active"],
                               "visited_pairs_per_pass": cs["bwd_visited"], "staged_list_entries_per_pass": cs["bwd_staged"],

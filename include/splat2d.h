@@ -270,6 +270,20 @@ int s2d_multi_create(const s2d_config* cfg, const int32_t* devices, int32_t n_de
 void s2d_multi_destroy(s2d_multi* m);
 const char* s2d_multi_last_error(const s2d_multi* m);
 int s2d_multi_device_count(const s2d_multi* m);
+/* Which GPU runs which rows: HIP device ordinal, row slab [row_begin, row_end), PCI bus id ("0000:c1:00.0") and marketing
+ * name of rank `rank`'s device (any output may be NULL; strings are truncated to their capacity).  What a host prints so
+ * that a multi-GPU record proves N distinct devices took part. */
+int s2d_multi_device_info(s2d_multi* m, int32_t rank, int32_t* device, int32_t* row_begin, int32_t* row_end, char* pci_bus_id,
+                          int32_t pci_capacity, char* name, int32_t name_capacity);
+/* A rank that stops answering must not hang the caller (the reference's only failure policy is abort(), main.cpp:752-785;
+ * this boundary turns failures into statuses, and "a rank stopped answering" is one of them).  Every wait of one rank for
+ * another -- for the event of its gradient exchange, at the rendezvous of a hold-set refresh -- and for its own stream
+ * gives up after `milliseconds` without progress: the step returns S2D_E_STATE, s2d_multi_last_error names the rank, the
+ * exchange / iteration and what it was last seen doing, communicators are aborted, and the handle refuses further work
+ * until it is destroyed and created again.  A rank that does not even answer the stop (it sits inside a runtime call) is
+ * abandoned after about three times the limit: the call still returns.  Default 30 000 (S2D_MULTI_STALL_TIMEOUT_MS in the
+ * environment overrides it at creation); 0 = wait without bound. */
+int s2d_multi_set_stall_timeout(s2d_multi* m, int32_t milliseconds);
 int s2d_multi_set_target(s2d_multi* m, const float* rgba32f);         /* imageRef, main.cpp:254-259, to every replica */
 int s2d_multi_set_target_synthetic(s2d_multi* m);
 int s2d_multi_init_splats(s2d_multi* m);                              /* init(), main.cpp:280-305, on every replica */

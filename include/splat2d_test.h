@@ -24,6 +24,11 @@ int s2d_test_exclusive_scan(int32_t device, uint32_t* data, int64_t n, uint64_t*
 int s2d_debug_get_tile_lists(s2d_ctx* ctx, int32_t* tiles_x, int32_t* tiles_y, uint32_t* offsets,
                              int64_t offsets_capacity, uint32_t* list, int64_t list_capacity);
 
+/* Failure injection for the multi-device handle: rank `rank`'s worker thread stops answering right after it has queued
+ * the raster launch of iteration `iteration` (before its gradient exchange) for `milliseconds` (< 0: until another rank has
+ * declared it gone).  rank < 0 clears the hook. */
+int s2d_test_multi_stall(s2d_multi* m, int32_t rank, int32_t iteration, int32_t milliseconds);
+
 #ifdef __cplusplus
 }
 #endif

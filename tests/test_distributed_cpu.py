@@ -289,3 +289,33 @@ def test_bench_spawns_its_ranks_from_the_plain_command():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode != 0
+
+
+def test_bench_watchdog_reports_a_rank_that_stops_answering():
+    """A rank that never comes back (here: it sleeps for ever right after the rendezvous; on hardware: a first-contact
+    RCCL or peer-to-peer stall) must not end as a silent kill at somebody else's time limit: the PARENT of `python
+    bench.py --gpus 2` -- which never touches the GPU -- stops the child group when its wall-clock budget runs out,
+    prints ONE JSON line with "error", the stage the ranks had reached and the last stderr lines, and exits non-zero."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["S2D_BENCH_SELFTEST_HANG_RANK"] = "1"
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest", "--watchdog-seconds", "25"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    dt = time.perf_counter() - t0
+    assert p.returncode != 0
+    assert dt < 25 + 30, dt                              # budget + the grace of the group kill, not torch's 10 minutes
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                        # still ONE JSON line
+    out = json.loads(lines[0])
+    assert out["value"] is None and "stopped answering" in out["error"], out
+    assert out["stage"] in ("init", "selftest"), out     # the furthest stage any rank reported
+    assert out["stage_per_rank"].get("1") == "init", out # the sleeping rank got as far as the rendezvous
+    assert out["n_gpus"] == 2 and out["attempts"][0]["rc"] is None and out["watchdog_budget_s"] == 25
+    # nothing of the job is left behind
+    left = subprocess.run(["ps", "-eo", "pid,args"], capture_output=True, text=True).stdout
+    assert not any("--launch-selftest" in ln and "--watchdog-seconds 25" in ln for ln in left.splitlines()), left

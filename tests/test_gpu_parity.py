@@ -1383,6 +1383,73 @@ def test_multi_device_handle_reports_nonfinite_like_the_single_context(replicate
         assert np.isfinite(m.step(2)).all()
 
 
+@pytest.mark.parametrize("world,replicated", [(2, False), (3, False), (2, True)])
+def test_multi_device_handle_reports_a_rank_that_stopped_answering(world, replicated):
+    """The reference's only failure policy is abort() (main.cpp:752-785); the boundary turns failures into statuses, and
+    "a rank stopped answering" is one of them: with a stall injected into one rank's worker thread (include/splat2d_test.h)
+    the step returns S2D_E_STATE inside the stall limit instead of hanging, the message names the rank and where the run
+    stood, the handle refuses further steps, and destroying it does not hang either.  A stall SHORTER than the limit is
+    just a slow rank: the run completes with the bits of an undisturbed one."""
+    import time
+    tgt = mini_target()
+    with S2D.MultiTrainer(268, 213, 1500, [0] * world, share_gpu=True, deterministic=True, replicated=replicated) as m:
+        m.set_target(tgt)
+        m.init()
+        want = np.concatenate([m.step(3), m.step(4)])
+    with S2D.MultiTrainer(268, 213, 1500, [0] * world, share_gpu=True, deterministic=True, replicated=replicated) as m:
+        m.set_target(tgt)
+        m.init()
+        m.set_stall_timeout(2000)
+        m.test_stall(world - 1, 1, 300)          # slow, not gone
+        got = np.concatenate([m.step(3), m.step(4)])
+        assert got.tobytes() == want.tobytes()
+        m.set_stall_timeout(400)
+        m.test_stall(world - 1, 9, -1)           # gone: until somebody declares it so
+        t0 = time.perf_counter()
+        with pytest.raises(S2D.S2DError) as ei:
+            m.step(5)
+        dt = time.perf_counter() - t0
+        assert ei.value.code == 5, ei.value      # S2D_E_STATE
+        msg = str(ei.value)
+        assert ("rank %d" % (world - 1)) in msg and ("stopped answering" in msg or "did not reach the rendezvous" in msg), msg
+        assert "iteration 9" in msg, msg
+        assert dt < 10.0, dt
+        with pytest.raises(S2D.S2DError) as ei2:
+            m.step(1)
+        assert ei2.value.code == 5 and "create a new one" in str(ei2.value)
+        t0 = time.perf_counter()
+    assert time.perf_counter() - t0 < 10.0       # close() came back
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_device_handle_free_running_exchange_with_ranks_at_different_speeds(world):
+    """Between refreshes the rank threads of a slab-ownership handle do not meet: they order the gradient exchange with
+    pairwise sequence counters, stream event waits and two send buffers (csrc/s2d_multi.hip exchange_grads).  Make the
+    ranks run at different speeds -- one rank's thread sleeps a few milliseconds at several iterations, another at
+    others -- across three refresh intervals: parameters, moments and trace must equal those of the replicated scheme
+    (whose sums are formed in the same rank order) bit for bit."""
+    out = {}
+    for replicated in (False, True):
+        with S2D.MultiTrainer(512, 768, 20000, [0] * world, share_gpu=True, deterministic=True, replicated=replicated) as m:
+            m.set_target_synthetic()
+            m.init()
+            tr = []
+            it = 0
+            for k in range(52):                    # 52 x 4 = 208 iterations: three refreshes
+                if not replicated:
+                    m.test_stall((k * 7) % world, it + (k % 4), 3 + k % 5)
+                tr.append(m.step(4))
+                it += 4
+            tr = np.concatenate(tr)
+            info = m.exchange_info()
+            out[replicated] = (tr.tobytes(), m.get_splats().tobytes(), m.get_adam()[0].tobytes())
+            if not replicated:
+                assert info["rows_per_iteration"] > 0 and info["state_handovers"] > 0, info
+            assert np.isfinite(tr).all() and tr[-1] < tr[0]
+    for k, name in enumerate(["trace", "splats", "adam"]):
+        assert out[False][k] == out[True][k], name
+
+
 @pytest.mark.parametrize("exchange", ["halo", "dense"])
 def test_cpp_host_run_control_works_on_the_multi_device_handle(tmp_path, exchange):
     """splat2d_train --gpus 3 --share-gpu with the options the single-GPU loop has: a checkpoint

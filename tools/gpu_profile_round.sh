@@ -7,7 +7,7 @@
 # and profiles/traffic.json for bench.py's roofline.traffic (tied to the kernel sources by their digest).
 # rocprofv3 is given `python3 bench.py ...` directly (no shell / env hop); counters are collected with --kernel-trace only.
 set -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/profile_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
@@ -25,6 +25,6 @@ python3 tools/profile_summarise.py stats "$out/stats" "$out/${tag}_kernel_stats.
 python3 tools/profile_summarise.py working "$out/stats" "$out/${tag}_kernel_working_launches.csv"
 python3 tools/profile_summarise.py pmc "$out/fetch" "$out/write" "$out/${tag}_pmc_traffic.csv"
 python3 tools/profile_summarise.py pmc "$out/sq1" "$out/sq2" "$out/${tag}_pmc_sq.csv"
-python3 tools/profile_summarise.py traffic "$out/${tag}_pmc_traffic.csv" "$out/traffic.json"
+python3 tools/profile_summarise.py traffic "$out/${tag}_pmc_traffic.csv" "$out/${tag}_pmc_sq.csv" "$out/traffic.json"
 grep -h '"metric"' "$out/stats.log" | tail -1 > "$out/${tag}_bench_under_rocprof.json"
 head -4 "$out/${tag}_kernel_stats.csv" | cut -c1-60,250-; cat "$out/traffic.json"

@@ -9,7 +9,7 @@
                  per kernel, from the kernel TRACE: all launches, and the launches that did work -- the first raster kernel of
                  an iteration is launched optimistically and returns at once (~22 us) when the tile lists turn out stale
                  (csrc/s2d_api.hip queue_raster), so the stats file's AverageNs mixes in one void launch per list rebuild
-  traffic      : profile_summarise.py traffic <pmc_traffic.csv> <traffic.json>
+  traffic      : profile_summarise.py traffic <pmc_traffic.csv> [<pmc_sq.csv>] <traffic.json>
                  HBM bytes per launch of the dominant raster kernel for bench.py's roofline.traffic, corrected as
                  /opt/skills/guides/MI355X_MICROARCH.md (HBM section) prescribes for gfx950, and tied to the kernel sources
 """
@@ -92,8 +92,23 @@ def main():
         rows = [r for r in csv.reader(l for l in open(sys.argv[2]) if not l.startswith("#"))]
         hdr, rows = rows[0], rows[1:]
         ifetch, iwrite = hdr.index("FETCH_SIZE"), hdr.index("WRITE_SIZE")
-        cand = [r for r in rows if "raster_fused_kernel<false; false; false; false>" in r[0]] or [r for r in rows if "raster_" in r[0]]
+        # the dominant kernel: the fused raster instantiation with the most launches (bench.py's timed block: all nine gradients)
+        cand = [r for r in rows if "raster_fused_kernel<" in r[0]] or [r for r in rows if "raster_" in r[0]]
         r = max(cand, key=lambda r: int(r[1]))
+        sq = {}
+        if len(sys.argv) > 4:   # the SQ / GRBM passes of the same kernel
+            srows = [x for x in csv.reader(l for l in open(sys.argv[3]) if not l.startswith("#"))]
+            shdr = srows[0]
+            hit = [x for x in srows[1:] if x[0] == r[0]]
+            if hit:
+                v = {c: float(hit[0][k]) for k, c in enumerate(shdr) if k >= 3 and hit[0][k] != ""}
+                cycles = v.get("GRBM_GUI_ACTIVE", 0.0) / 8.0          # the counter is read per XCD and summed: 8 XCDs
+                sq = {"sq_source": "%s (rocprofv3 --pmc, two SQ/GRBM passes)" % os.path.basename(sys.argv[3]),
+                      "SQ_INSTS_VALU_per_launch": v.get("SQ_INSTS_VALU"), "SQ_INSTS_SALU_per_launch": v.get("SQ_INSTS_SALU"),
+                      "SQ_INSTS_LDS_per_launch": v.get("SQ_INSTS_LDS"), "SQ_LDS_BANK_CONFLICT_per_launch": v.get("SQ_LDS_BANK_CONFLICT"),
+                      "gpu_cycles_per_launch": cycles,
+                      # 256 CUs x 4 SIMDs issue at most one VALU instruction per cycle each
+                      "simd_cycles_per_valu_instruction": (1024.0 * cycles / v["SQ_INSTS_VALU"]) if v.get("SQ_INSTS_VALU") else None}
         fetch_kb, write_kb = float(r[ifetch]), float(r[iwrite])
         import importlib
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -112,8 +127,9 @@ def main():
             "dominant_kernel_bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
             "kernel_source_digest": digest,
         }
-        json.dump(out, open(sys.argv[3], "w"), indent=1)
-        print("wrote", sys.argv[3])
+        out.update(sq)
+        json.dump(out, open(sys.argv[-1], "w"), indent=1)
+        print("wrote", sys.argv[-1])
     else:
         raise SystemExit(__doc__)
 
