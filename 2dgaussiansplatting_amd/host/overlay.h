@@ -27,45 +27,92 @@ inline void draw_line(Image8* im, float x0, float y0, float x1, float y1, const 
     }
 }
 
-// scale: output pixels per image pixel (the GUI's viewScale, main.cpp:822); `im` must already be that size.
-inline void draw_splat_overlay(Image8* im, const std::vector<s2d_splat>& splats, int scale, int stride = 1)
+// One vertex as the reference hands it to pr::PrimVertex(glm::vec3, glm::u8vec3): scene coordinates (x, -y, 0) -- the
+// reference's camera looks at a y-up plane, main.cpp:447 -- and an 8-bit colour.
+struct OverlayVertex {
+    float x, y, z;
+    uint8_t r, g, b, pad;
+};
+constexpr int kOverlayVertices = 46; // per splat: 2 axes + 17 ellipse segments + 4 box sides, two vertices each
+
+// The vertex list of main.cpp:419-477 for one splat, in the reference's call order and with its arithmetic: cov_of
+// (:206-221), eignValues (:188-196), the inverse (:432-436), eigen_vectors_of_cov (:223-234; glm::normalize(v) =
+// v * (1 / sqrt(dot(v, v)))), the axes (:443-451), the 16-gon (:454-462; pr::CircleGenerator = the angle-addition
+// recurrence from (sin, cos) = (0, 1)), the box (:464-477).  tests/test_host_io_cpu.py compares these bit for bit with
+// the oracle's restatement (oracle/s2d_oracle.c s2do_overlay_vertices).
+inline void overlay_vertices(const s2d_splat& s, OverlayVertex* out)
+{
+    struct V3 {
+        float x, y, z;
+        V3 operator+(const V3& o) const { return {x + o.x, y + o.y, z + o.z}; }
+        V3 operator*(float k) const { return {x * k, y * k, z * k}; }
+    };
+    int n = 0;
+    const auto put = [&](const V3& p, unsigned r, unsigned g, unsigned b) {
+        out[n++] = OverlayVertex{p.x, p.y, p.z, (uint8_t)r, (uint8_t)g, (uint8_t)b, 0};
+    };
+    const float ct = std::cos(s.rot), st = std::sin(s.rot);
+    const float lam_x = s.sx * s.sx, lam_y = s.sy * s.sy;
+    const float s11 = lam_x * ct * ct + lam_y * st * st;
+    const float s12 = (lam_x - lam_y) * st * ct;
+    const float s22 = lam_x + lam_y - s11;
+    const float mean = (s11 + s22) * 0.5f;
+    const float det = s11 * s22 - s12 * s12;
+    const float disc = mean * mean - det;
+    const float half_gap = std::sqrt(disc < 0.0f ? 0.0f : disc); // ss_max(x, 0) = (x < 0) ? 0 : x
+    const float big = mean + half_gap, small = mean - half_gap;
+    const float r_big = std::sqrt(big), r_small = std::sqrt(small);
+    const float i00 = s22 / det, i11 = s11 / det;
+    const float eps = 1e-15f;
+    const bool tall = s11 < s22;
+    const float ux = tall ? s12 + eps : big - s22, uy = tall ? big - s11 : s12 + eps;
+    const float scale = 1.0f / std::sqrt(ux * ux + uy * uy);
+    const float e0x = ux * scale, e0y = uy * scale;
+    const V3 centre{s.pos[0], -s.pos[1], 0.0f};
+    const V3 major{e0x * r_big, -(e0y * r_big), 0.0f};
+    const V3 minor{-e0y * r_small, -(e0x * r_small), 0.0f};
+    put(centre, 255, 255, 255);
+    put(centre + major, 255, 255, 255);
+    put(centre, 255, 255, 255);
+    put(centre + minor, 230, 230, 230);
+    const unsigned cr = (unsigned)(s.color[0] * 255.0f), cg = (unsigned)(s.color[1] * 255.0f), cb = (unsigned)(s.color[2] * 255.0f);
+    const int sides = 16;
+    const float dtheta = 3.14159265358979323846264338327950288f * 2.0f / sides;
+    const float sd = std::sin(dtheta), cd = std::cos(dtheta);
+    float sn = 0.0f, cs = 1.0f;
+    for (int k = 0; k <= sides; k++) {
+        put(centre + major * sn + minor * cs, cr, cg, cb);
+        const float sn2 = sn * cd + cs * sd, cs2 = cs * cd - sn * sd;
+        sn = sn2;
+        cs = cs2;
+        put(centre + major * sn + minor * cs, cr, cg, cb);
+    }
+    const float hx = std::sqrt(i11 * det), hy = std::sqrt(i00 * det);
+    const V3 corner[4] = {{-hx, -hy, 0.0f}, {hx, -hy, 0.0f}, {hx, hy, 0.0f}, {-hx, hy, 0.0f}};
+    for (int k = 0; k < 4; k++) {
+        put(centre + corner[k], 128, 128, 128);
+        put(centre + corner[(k + 1) & 3], 128, 128, 128);
+    }
+}
+
+// scale: output pixels per image pixel (the GUI's viewScale, main.cpp:822); `im` must already be that size.  Every pair
+// of vertices is one line (PrimitiveMode::Lines, main.cpp:416), drawn in its second vertex's colour; scene y is image -y.
+// `dump` (optional) receives the vertices as drawn, kOverlayVertices per splat.
+inline void draw_splat_overlay(Image8* im, const std::vector<s2d_splat>& splats, int scale, int stride = 1,
+                               std::vector<OverlayVertex>* dump = nullptr)
 {
     const float S = (float)scale;
+    OverlayVertex v[kOverlayVertices];
     for (size_t i = 0; i < splats.size(); i += (size_t)(stride < 1 ? 1 : stride)) {
-        const s2d_splat& s = splats[i];
-        // cov_of, main.cpp:206-221
-        const float c = std::cos(s.rot), sn = std::sin(s.rot);
-        const float l0 = s.sx * s.sx, l1 = s.sy * s.sy;
-        const float s11 = l0 * c * c + l1 * sn * sn, s12 = (l0 - l1) * sn * c, s22 = l0 + l1 - s11;
-        // eignValues, main.cpp:188-196
-        const float mean = (s11 + s22) * 0.5f, det = s11 * s22 - s12 * s12;
-        const float d = std::sqrt(std::fmax(mean * mean - det, 0.0f));
-        const float lambda0 = mean + d, lambda1 = mean - d;
-        // eigen_vectors_of_cov, main.cpp:223-234
-        const float eps = 1e-15f;
-        float ex = s11 < s22 ? s12 + eps : lambda0 - s22, ey = s11 < s22 ? lambda0 - s11 : s12 + eps;
-        const float len = std::sqrt(ex * ex + ey * ey);
-        if (!(len > 0.0f) || !std::isfinite(len)) continue;
-        ex /= len; ey /= len;
-        const float a0x = ex * std::sqrt(lambda0), a0y = ey * std::sqrt(lambda0);             // axis0, main.cpp:443
-        const float a1x = -ey * std::sqrt(std::fmax(lambda1, 0.0f)), a1y = ex * std::sqrt(std::fmax(lambda1, 0.0f)); // axis1, :444
-        const float px = s.pos[0] * S, py = s.pos[1] * S;
-        const uint8_t white[3] = {255, 255, 255}, light[3] = {230, 230, 230}, grey[3] = {128, 128, 128};
-        draw_line(im, px, py, px + a0x * S, py + a0y * S, white);                             // main.cpp:447-448
-        draw_line(im, px, py, px + a1x * S, py + a1y * S, light);                             // main.cpp:450-451
-        const uint8_t col[3] = {(uint8_t)(s.color[0] * 255.0f), (uint8_t)(s.color[1] * 255.0f), (uint8_t)(s.color[2] * 255.0f)};
-        const int nvtx = 16;                                                                  // main.cpp:454-462
-        for (int k = 0; k < nvtx; k++) {
-            const float t0 = 6.2831853f * k / nvtx, t1 = 6.2831853f * (k + 1) / nvtx;
-            draw_line(im, px + (a0x * std::sin(t0) + a1x * std::cos(t0)) * S, py + (a0y * std::sin(t0) + a1y * std::cos(t0)) * S,
-                      px + (a0x * std::sin(t1) + a1x * std::cos(t1)) * S, py + (a0y * std::sin(t1) + a1y * std::cos(t1)) * S, col);
+        overlay_vertices(splats[i], v);
+        if (dump) dump->insert(dump->end(), v, v + kOverlayVertices);
+        bool finite = true;
+        for (const OverlayVertex& q : v) finite = finite && std::isfinite(q.x) && std::isfinite(q.y);
+        if (!finite) continue;
+        for (int k = 0; k + 1 < kOverlayVertices; k += 2) {
+            const uint8_t c[3] = {v[k + 1].r, v[k + 1].g, v[k + 1].b};
+            draw_line(im, v[k].x * S, -v[k].y * S, v[k + 1].x * S, -v[k + 1].y * S, c);
         }
-        // exact bounding box from the covariance: sqrt(inv_cov[1][1]*det) = sqrt(s11), sqrt(inv_cov[0][0]*det) = sqrt(s22); main.cpp:464-477
-        const float hx = std::sqrt(std::fmax(s11, 0.0f)) * S, hy = std::sqrt(std::fmax(s22, 0.0f)) * S;
-        draw_line(im, px - hx, py - hy, px + hx, py - hy, grey);
-        draw_line(im, px + hx, py - hy, px + hx, py + hy, grey);
-        draw_line(im, px + hx, py + hy, px - hx, py + hy, grey);
-        draw_line(im, px - hx, py + hy, px - hx, py - hy, grey);
     }
 }
 

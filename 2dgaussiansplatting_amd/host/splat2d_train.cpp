@@ -44,6 +44,7 @@ struct Options {
     std::string overlay;        // --overlay file: image0 upscaled by overlay_scale with the splat debug drawing (main.cpp:441-485)
     int overlay_scale = 2;      // viewScale, main.cpp:822
     int overlay_stride = 1;     // draw every k-th splat
+    std::string overlay_dump;   // --overlay-vertices file: the pr::PrimVertex list of main.cpp:447-476 as drawn (binary, see below)
     std::string convert_in, convert_out; // --convert in out: image conversion only (no GPU)
     std::string load_ckpt, save_ckpt; // the five objects of main.cpp:272-278: splats, splatAdams, beta1t, beta2t, iterations
     int device = 0;
@@ -67,7 +68,7 @@ int usage()
     std::fprintf(stderr,
                  "usage: splat2d_train (--image file.s2di|.ppm|.png|.jpg | --synthetic WxH) [--splats N] [--iters K] [--batch B]\n"
                  "                     [--optimize-opacity [--opacity-from IT]] [--restart-at IT] [--out-image file.png|.ppm]\n"
-                 "                     [--overlay file [--overlay-scale S] [--overlay-stride K]]\n"
+                 "                     [--overlay file [--overlay-scale S] [--overlay-stride K] [--overlay-vertices file]]\n"
                  "       splat2d_train --convert in.(s2di|ppm|png|jpg) out.(s2di|ppm|png)\n"
                  "                     [--load-checkpoint file] [--save-checkpoint file]\n"
                  "                     [--device D] [--gpus N [--exchange halo|dense] [--share-gpu]] [--rebin-interval R] [--quiet]\n");
@@ -177,6 +178,7 @@ int main(int argc, char** argv)
         else if (a == "--overlay") o.overlay = next("--overlay");
         else if (a == "--overlay-scale") o.overlay_scale = std::atoi(next("--overlay-scale"));
         else if (a == "--overlay-stride") o.overlay_stride = std::atoi(next("--overlay-stride"));
+        else if (a == "--overlay-vertices") o.overlay_dump = next("--overlay-vertices");
         else if (a == "--convert") { o.convert_in = next("--convert"); o.convert_out = next("--convert"); }
         else if (a == "--load-checkpoint") o.load_ckpt = next("--load-checkpoint");
         else if (a == "--save-checkpoint") o.save_ckpt = next("--save-checkpoint");
@@ -303,7 +305,21 @@ int main(int argc, char** argv)
             std::vector<s2d_splat> sp((size_t)o.n_splats);
             CK(S.get_splats(sp.data()));
             s2dio::Image8 big = s2dio::upscale(im, o.overlay_scale);
-            s2dio::draw_splat_overlay(&big, sp, o.overlay_scale, o.overlay_stride);
+            std::vector<s2dio::OverlayVertex> verts;
+            s2dio::draw_splat_overlay(&big, sp, o.overlay_scale, o.overlay_stride, o.overlay_dump.empty() ? nullptr : &verts);
+            if (!o.overlay_dump.empty()) {
+                // "S2DV", int32 vertex count, then 16 bytes per vertex: float x, y, z (scene coordinates of main.cpp:447:
+                // x, -y, 0), uint8 r, g, b, 0 -- 46 vertices per drawn splat, in the reference's PrimVertex order
+                FILE* f = std::fopen(o.overlay_dump.c_str(), "wb");
+                const int32_t count = (int32_t)verts.size();
+                const bool ok = f && std::fwrite("S2DV", 1, 4, f) == 4 && std::fwrite(&count, 4, 1, f) == 1 &&
+                                std::fwrite(verts.data(), sizeof(s2dio::OverlayVertex), verts.size(), f) == verts.size();
+                if (f) std::fclose(f);
+                if (!ok) {
+                    std::fprintf(stderr, "cannot write %s\n", o.overlay_dump.c_str());
+                    exit_code = 1;
+                }
+            }
             if (!s2dio::save_image(o.overlay, big)) {
                 std::fprintf(stderr, "cannot write %s\n", o.overlay.c_str());
                 exit_code = 1;

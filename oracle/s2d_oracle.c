@@ -489,3 +489,79 @@ int s2do_step_mt(s2do_splat* splats, s2do_splat_adam* adams, int n, int W, int H
     if (mse_out) *mse_out = s2do_mse(image0, image_ref, W, H);
     return st;
 }
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * The per-splat debug drawing, main.cpp:419-477 (see s2d_oracle.h).  Every expression below is the reference's, in its
+ * order; glm::vec3 + glm::vec3 * float + glm::vec3 * float evaluates left to right, component by component.
+ * ---------------------------------------------------------------------------------------------------------------- */
+typedef struct { float x, y, z; } ov3;
+static inline ov3 ov_add(ov3 a, ov3 b) { ov3 r = { a.x + b.x, a.y + b.y, a.z + b.z }; return r; }
+static inline ov3 ov_mul(ov3 a, float s) { ov3 r = { a.x * s, a.y * s, a.z * s }; return r; }
+
+static void ov_emit(float** xyz, uint8_t** rgb, ov3 p, unsigned r, unsigned g, unsigned b)
+{
+    (*xyz)[0] = p.x; (*xyz)[1] = p.y; (*xyz)[2] = p.z;
+    (*rgb)[0] = (uint8_t)r; (*rgb)[1] = (uint8_t)g; (*rgb)[2] = (uint8_t)b; /* glm::u8vec3 from ints / from a uvec3 */
+    *xyz += 3;
+    *rgb += 3;
+}
+
+void s2do_overlay_vertices(const s2do_splat* splats, int n, float* xyz, uint8_t* rgb)
+{
+    const float pi = 3.14159265358979323846264338327950288f; /* glm::pi<float>() */
+    for (int i = 0; i < n; i++) {
+        const s2do_splat s = splats[i];                       /* main.cpp:421 */
+        /* cov_of, main.cpp:206-221 */
+        const float cosTheta = cosf(s.rot), sinTheta = sinf(s.rot);
+        const float l0 = s.sx * s.sx, l1 = s.sy * s.sy;
+        const float s11 = l0 * cosTheta * cosTheta + l1 * sinTheta * sinTheta;
+        const float s12 = (l0 - l1) * sinTheta * cosTheta;
+        const float s22 = l0 + l1 - s11;
+        /* eignValues, main.cpp:188-196 (mat[0][0] = s11, mat[1][1] = s22, mat[1][0] = mat[0][1] = s12) */
+        const float mean = (s11 + s22) * 0.5f;
+        const float det = s11 * s22 - s12 * s12;
+        const float d = sqrtf(ss_max(mean * mean - det, 0.0f));
+        const float lambda0 = mean + d, lambda1 = mean - d;
+        const float sqrt_of_lambda0 = sqrtf(lambda0), sqrt_of_lambda1 = sqrtf(lambda1); /* main.cpp:429-430 */
+        /* inv_cov = mat2(cov[1][1], -cov[0][1], -cov[1][0], cov[0][0]) / det, main.cpp:432-436 */
+        const float inv00 = s22 / det, inv11 = s11 / det;
+        /* eigen_vectors_of_cov, main.cpp:223-234 */
+        const float eps = 1e-15f;
+        float ex, ey;
+        if (s11 < s22) { ex = s12 + eps; ey = lambda0 - s11; }
+        else           { ex = lambda0 - s22; ey = s12 + eps; }
+        const float inv_len = 1.0f / sqrtf(ex * ex + ey * ey); /* glm::normalize: v * inversesqrt(dot(v, v)) */
+        const float e0x = ex * inv_len, e0y = ey * inv_len;
+        const float e1x = -e0y, e1y = e0x;
+        /* main.cpp:443-444 */
+        const float axis0x = e0x * sqrt_of_lambda0, axis0y = e0y * sqrt_of_lambda0;
+        const float axis1x = e1x * sqrt_of_lambda1, axis1y = e1y * sqrt_of_lambda1;
+        const ov3 P = { s.pos_x, -s.pos_y, 0.0f };
+        const ov3 A0 = { axis0x, -axis0y, 0.0f }, A1 = { axis1x, -axis1y, 0.0f };
+        /* axes, main.cpp:447-451 */
+        ov_emit(&xyz, &rgb, P, 255, 255, 255);
+        ov_emit(&xyz, &rgb, ov_add(P, A0), 255, 255, 255);
+        ov_emit(&xyz, &rgb, P, 255, 255, 255);
+        ov_emit(&xyz, &rgb, ov_add(P, A1), 230, 230, 230);
+        /* ellipse, main.cpp:454-462; glm::uvec3 col = s.color * 255.0f, then u8vec3 at the call */
+        const int nvtx = 16;
+        const float step = pi * 2.0f / nvtx;
+        const float sd = sinf(step), cd = cosf(step);          /* pr::CircleGenerator (prlib, absent: see header) */
+        float cs = 0.0f, cc = 1.0f;
+        const unsigned cr = (unsigned)(s.col_r * 255.0f), cg = (unsigned)(s.col_g * 255.0f), cb = (unsigned)(s.col_b * 255.0f);
+        for (int k = 0; k <= nvtx; k++) {
+            ov_emit(&xyz, &rgb, ov_add(ov_add(P, ov_mul(A0, cs)), ov_mul(A1, cc)), cr, cg, cb);
+            const float ns = cs * cd + cc * sd, nc = cc * cd - cs * sd;
+            cs = ns;
+            cc = nc;
+            ov_emit(&xyz, &rgb, ov_add(ov_add(P, ov_mul(A0, cs)), ov_mul(A1, cc)), cr, cg, cb);
+        }
+        /* the exact 1-sigma bounding box, main.cpp:464-477 */
+        const float hx = sqrtf(inv11 * det), hy = sqrtf(inv00 * det);
+        const ov3 vs[4] = { { -hx, -hy, 0.0f }, { +hx, -hy, 0.0f }, { +hx, +hy, 0.0f }, { -hx, +hy, 0.0f } };
+        for (int k = 0; k < 4; k++) {
+            ov_emit(&xyz, &rgb, ov_add(P, vs[k]), 128, 128, 128);
+            ov_emit(&xyz, &rgb, ov_add(P, vs[(k + 1) % 4]), 128, 128, 128);
+        }
+    }
+}

@@ -116,6 +116,20 @@ void s2do_set_adam_fp32(int on);
 /* main.cpp:51: switch exp_approx to expf for every later call ("use this for numerical varidation"). */
 void s2do_set_exact_exp(int on);
 
+/* The per-splat debug drawing of the forward loop, main.cpp:419-477: the vertices the
+ * reference hands to pr::PrimVertex(glm::vec3, glm::u8vec3) for splat s, in call order -- 2 axis segments (main.cpp:447-451),
+ * 17 segments of the 16-gon (the loop runs i = 0..nvtx inclusive, main.cpp:457-462) and the 4 sides of the 1-sigma box
+ * (main.cpp:464-477): S2DO_OVERLAY_VERTICES = 46 vertices per splat.  xyz gets 3 floats per vertex in the reference's
+ * scene coordinates (x, -y, 0); rgb 3 bytes per vertex.  Restated from main.cpp: cov_of :206-221, eignValues :188-196,
+ * eigen_vectors_of_cov :223-234, the inverse :432-436.  Restated from third-party code ABSENT from /root/reference
+ * (prlib, un-vendored submodule, pinned commit not recoverable): pr::CircleGenerator, as the
+ * angle-addition recurrence its published source implements (sin, cos start at 0, 1; step(): s' = s*cd + c*sd,
+ * c' = c*cd - s*sd with sd, cd = sin, cos of the step angle), and glm::normalize(v) = v * (1 / sqrt(dot(v, v))).
+ * The axes and the box depend on main.cpp's own arithmetic only; the 16-gon's vertices are "parity unpinned" with
+ * respect to prlib's arithmetic. */
+#define S2DO_OVERLAY_VERTICES 46
+void s2do_overlay_vertices(const s2do_splat* splats, int n, float* xyz, uint8_t* rgb);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,7 @@
 // with the oracle on a machine without a GPU.  It is not a CPU fallback: the product
 // library never links or calls this file.
 #include "../../2dgaussiansplatting_amd/csrc/s2d_math.h"
+#include "../../2dgaussiansplatting_amd/host/overlay.h" // the host program's vertex list of main.cpp:447-476 (row f3)
 
 #include <cstring>
 
@@ -83,6 +84,22 @@ int hc_check_bounds(const float* splats9, int n, int W, int H)
         }
     }
     return bad;
+}
+
+// The host program's overlay vertices (host/overlay.h overlay_vertices) for n splats: 46 x (3 floats, 3 bytes) each.
+void hc_overlay_vertices(const float* splats9, int n, float* xyz, unsigned char* rgb)
+{
+    for (int i = 0; i < n; i++) {
+        s2d_splat sp;
+        std::memcpy(&sp, splats9 + 9 * (size_t)i, sizeof(sp));
+        s2dio::OverlayVertex v[s2dio::kOverlayVertices];
+        s2dio::overlay_vertices(sp, v);
+        for (int k = 0; k < s2dio::kOverlayVertices; k++) {
+            const size_t at = (size_t)i * s2dio::kOverlayVertices + (size_t)k;
+            xyz[3 * at] = v[k].x, xyz[3 * at + 1] = v[k].y, xyz[3 * at + 2] = v[k].z;
+            rgb[3 * at] = v[k].r, rgb[3 * at + 1] = v[k].g, rgb[3 * at + 2] = v[k].b;
+        }
+    }
 }
 
 } // extern "C"

@@ -53,6 +53,7 @@ def lib():
     L.s2do_pcg3d.argtypes = [vp]
     L.s2do_set_exact_exp.argtypes = [i]
     L.s2do_set_adam_fp32.argtypes = [i]
+    L.s2do_overlay_vertices.argtypes = [vp, i, vp, vp]
     _lib = L
     return L
 
@@ -268,3 +269,27 @@ def step_delta_error(before, got_after, want_after, lr=0.05):
     d = np.abs((g - b) - (w - b))
     d = np.maximum(d - ulp32(want_after), 0.0)
     return d / lr
+
+
+OVERLAY_VERTICES = 46  # S2DO_OVERLAY_VERTICES: 2 axes + 17 segments of the 16-gon + 4 box sides, two vertices each
+
+
+def overlay_vertices(splats):
+    """The reference's PrimVertex list (main.cpp:447-476) for these splats, from the oracle's restatement: (xyz float32
+    [n*46, 3] in scene coordinates (x, -y, 0), rgb uint8 [n*46, 3])."""
+    L = lib()
+    sp = np.ascontiguousarray(splats).view(np.float32).reshape(-1, 9)
+    n = sp.shape[0]
+    xyz = np.zeros((n * OVERLAY_VERTICES, 3), dtype=np.float32)
+    rgb = np.zeros((n * OVERLAY_VERTICES, 3), dtype=np.uint8)
+    L.s2do_overlay_vertices(_p(sp), n, _p(xyz), _p(rgb))
+    return xyz, rgb
+
+
+def read_overlay_dump(path):
+    """`splat2d_train --overlay-vertices` file: "S2DV", int32 count, count x (3 float32, 4 uint8)."""
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"S2DV"
+    count = int(np.frombuffer(raw, dtype=np.int32, count=1, offset=4)[0])
+    rec = np.frombuffer(raw, dtype=np.dtype([("xyz", np.float32, 3), ("rgb", np.uint8, 4)]), count=count, offset=8)
+    return rec["xyz"].copy(), rec["rgb"][:, :3].copy()

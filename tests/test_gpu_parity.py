@@ -785,6 +785,36 @@ def test_cpp_host_png_target_and_overlay(tmp_path):
     assert (ov[changed] == 128).all(axis=1).any() and (ov[changed] == 255).all(axis=1).any()  # grey boxes, white axes
 
 
+def _checkpoint_splats(path, n):
+    """The splat records of a splat2d_train checkpoint (host/splat2d_train.cpp CkptHeader: 28-byte header, then n x 36 bytes)."""
+    raw = open(path, "rb").read()
+    assert raw[:4] == b"S2DC" and len(raw) == 28 + n * (36 + 72), len(raw)
+    return np.frombuffer(raw, dtype=O.SPLAT_DTYPE, count=n, offset=28).copy()
+
+
+@pytest.mark.parametrize("iters", [0, 10])
+def test_cpp_host_overlay_vertices_are_the_references_primvertex_list(tmp_path, iters):
+    """splat2d_train --overlay-vertices dumps the line segments its overlay draws: for the mini scene at iteration 0 and
+    after 10 steps they must be, bit for bit, the oracle's restatement of main.cpp:419-477 (eigen_vectors_of_cov :223-234,
+    axes :443-451, 16-gon :454-462, 1-sigma box :464-477) evaluated on the splats the run ended with (its checkpoint):
+    floats bitwise, colours as the u8 triples.  The rasterisation itself stays covered by the property test above."""
+    import subprocess
+    exe = S2D._build.build_host_program()
+    ck, dump = str(tmp_path / "s.ckpt"), str(tmp_path / "v.bin")
+    r = subprocess.run([exe, "--image", MINI, "--splats", "1024", "--iters", str(iters), "--save-checkpoint", ck,
+                        "--overlay", str(tmp_path / "ov.ppm"), "--overlay-vertices", dump], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    splats = _checkpoint_splats(ck, 1024)
+    xyz, rgb = O.read_overlay_dump(dump)
+    want_xyz, want_rgb = O.overlay_vertices(splats)
+    assert xyz.shape == (1024 * O.OVERLAY_VERTICES, 3)
+    assert xyz.view(np.uint32).tolist() == want_xyz.view(np.uint32).tolist()
+    assert rgb.tobytes() == want_rgb.tobytes()
+    if iters == 0:   # the state init() leaves (main.cpp:280-305) is the oracle's
+        o = O.OracleTrainer(mini_target(), 1024)
+        assert splats.tobytes() == o.splats.tobytes()
+
+
 # ---------------------------------------------------------------------------------------------
 # S2D_CFG_FP16_IMAGES (BASELINE configs[4]: "fp16 color / fp32 grads")
 # ---------------------------------------------------------------------------------------------

@@ -21,10 +21,11 @@ HC_DIR = os.path.join(HERE, "hostcheck")
 def hc():
     so = os.path.join(HC_DIR, "libs2d_hostcheck.so")
     srcs = [os.path.join(HC_DIR, "s2d_hostcheck.cpp"),
-            os.path.join(O.ROOT, "2dgaussiansplatting_amd", "csrc", "s2d_math.h")]
+            os.path.join(O.ROOT, "2dgaussiansplatting_amd", "csrc", "s2d_math.h"),
+            os.path.join(O.ROOT, "2dgaussiansplatting_amd", "host", "overlay.h")]
     if not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(s) for s in srcs):
-        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-                               "-o", so, srcs[0], "-lm"])
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-I", os.path.join(O.ROOT, "include"),
+                               "-o", so, srcs[0], "-lm", "-lz"])
     L = C.CDLL(so)
     L.hc_adam.restype = C.c_float
     L.hc_adam.argtypes = [C.c_void_p, C.c_void_p] + [C.c_float] * 5
@@ -152,3 +153,74 @@ def test_adam_scalar_bitwise(hc):
                 assert np.float32(v.value) == a.view(np.float32).reshape(n, 9, 2)[i, k, 1]
         s2[:] = s
         a2[:] = a
+
+
+# ---------------------------------------------------------------------------------------------
+# row f3: the splat overlay's vertices (host/overlay.h) against the oracle's restatement of main.cpp:419-477
+# ---------------------------------------------------------------------------------------------
+def _overlay_cases():
+    o = O.OracleTrainer(O.target_rgba32f(O.load_s2di(os.path.join(O.GOLDEN, "squirrel_cls_mini_268x213.s2di"))), 1024)
+    init = o.splats.copy()
+    for _ in range(10):
+        o.step()
+    trained = o.splats.copy()
+    rng = np.random.default_rng(7)
+    odd = np.zeros(64, dtype=O.SPLAT_DTYPE)
+    odd["pos"] = rng.uniform(-20, 300, (64, 2))
+    odd["sx"] = rng.choice([1.0, 1.0000001, 3.5, 1024.0, 7.25], 64)
+    odd["sy"] = rng.choice([1.0, 2.0, 3.5, 1024.0, 7.25], 64)           # sx == sy: s12 = 0, the eps of main.cpp:229 decides
+    odd["rot"] = rng.choice([0.0, 1e-8, np.pi / 2, -3.0, 100.0, 0.7853982], 64)
+    odd["color"] = rng.uniform(0, 1, (64, 3))
+    odd["opacity"] = 1.0
+    return [("init", init), ("after 10 iterations", trained), ("degenerate", odd)]
+
+
+def test_overlay_vertices_equal_the_reference_restatement_bit_for_bit(hc):
+    """The 46 PrimVertex calls per splat of main.cpp:447-476 -- the two axes pos +- eigen * sqrt(lambda) (:443-451), the
+    16-gon (:454-462) and the 1-sigma box (:464-477) -- as the host program draws them (host/overlay.h), against the
+    oracle's restatement (oracle/s2d_oracle.c): floats bitwise, colours as the u8 triples.  Fails if an axis end point,
+    an ellipse vertex or a box corner moves by one ulp."""
+    hc.hc_overlay_vertices.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    for name, splats in _overlay_cases():
+        want_xyz, want_rgb = O.overlay_vertices(splats)
+        sp = np.ascontiguousarray(splats).view(np.float32).reshape(-1, 9)
+        xyz = np.zeros_like(want_xyz)
+        rgb = np.zeros_like(want_rgb)
+        hc.hc_overlay_vertices(p(sp), sp.shape[0], p(xyz), p(rgb))
+        assert xyz.view(np.uint32).tolist() == want_xyz.view(np.uint32).tolist(), name
+        assert rgb.tobytes() == want_rgb.tobytes(), name
+
+
+def test_overlay_vertices_have_the_reference_structure():
+    """What the restatement must reproduce of main.cpp:441-477, checked on the oracle's list itself: vertex order and
+    colours (:447-451, :473-474), the closed 17-segment 16-gon around pos whose first vertex is pos + axis1 (sin 0 = 0,
+    cos 0 = 1, :459), orthogonal axes of length sqrt(lambda), the box half sizes sqrt(s11), sqrt(s22) (Form.pdf section 12)."""
+    for name, splats in _overlay_cases()[:2]:
+        xyz, rgb = O.overlay_vertices(splats)
+        n = len(splats)
+        v = xyz.reshape(n, 46, 3).astype(np.float64)
+        c = rgb.reshape(n, 46, 3)
+        sp = splats.view(np.float32).reshape(-1, 9).astype(np.float64)
+        pos = np.stack([sp[:, 0], -sp[:, 1]], axis=1)
+        assert (v[:, :, 2] == 0).all()
+        assert (v[:, 0, :2] == pos).all() and (v[:, 2, :2] == pos).all()
+        assert (c[:, 0:3] == 255).all() and (c[:, 3] == 230).all() and (c[:, 38:] == 128).all()
+        assert (c[:, 4:38] == (splats["color"] * np.float32(255.0)).astype(np.uint32).astype(np.uint8)[:, None, :]).all()
+        a0, a1 = v[:, 1, :2] - pos, v[:, 3, :2] - pos
+        l0, l1 = np.maximum(sp[:, 2], sp[:, 3]) ** 2, np.minimum(sp[:, 2], sp[:, 3]) ** 2
+        np.testing.assert_allclose((a0 ** 2).sum(1), l0, rtol=2e-3)     # |axis0|^2 = lambda0 (the larger), main.cpp:443
+        np.testing.assert_allclose((a1 ** 2).sum(1), l1, rtol=2e-3, atol=2e-3)
+        assert (np.abs((a0 * a1).sum(1)) <= 1e-5 * np.sqrt(l0 * l1)).all()
+        ell = v[:, 4:38, :2]
+        np.testing.assert_array_equal(ell[:, 1:-1:2], ell[:, 2::2])     # a polyline: each segment starts where the last ended
+        np.testing.assert_allclose(ell[:, 0] - pos, a1, atol=1e-4)      # circular.sin() = 0, .cos() = 1 at the start
+        np.testing.assert_allclose(ell[:, 32], ell[:, 0], atol=2e-3)    # closed after 16 steps (the 17th segment repeats the first)
+        # the box: corners (-hx,-hy) (hx,-hy) (hx,hy) (-hx,hy), hx^2 = s11, hy^2 = s22 (cov_of, main.cpp:206-221)
+        ct, st = np.cos(sp[:, 4]), np.sin(sp[:, 4])
+        s11 = sp[:, 2] ** 2 * ct * ct + sp[:, 3] ** 2 * st * st
+        s22 = sp[:, 2] ** 2 + sp[:, 3] ** 2 - s11
+        box = v[:, 38:, :2] - pos[:, None, :]
+        np.testing.assert_allclose(box[:, 0], np.stack([-np.sqrt(s11), -np.sqrt(s22)], 1), rtol=1e-4)
+        np.testing.assert_allclose(box[:, 3], np.stack([np.sqrt(s11), np.sqrt(s22)], 1), rtol=1e-4)
+        np.testing.assert_array_equal(box[:, 1:-1:2], box[:, 2::2])
+        np.testing.assert_array_equal(box[:, 7], box[:, 0])
