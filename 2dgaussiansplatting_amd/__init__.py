@@ -284,7 +284,7 @@ class Trainer:
 
     def __init__(self, width, height, n_splats, device=0, row_begin=0, row_end=0, training_rate=0.0,
                  rebin_interval=0, rebin_margin=0.0, count_pairs=False, fp16_images=False, deterministic=False, exact_exp=False,
-                 adam_fp32=False, generic_binning=False, stream=None):
+                 adam_fp32=False, generic_binning=False, stream=None, chunk_pairs=None):
         self.L = load_library()
         self.W, self.H, self.n = int(width), int(height), int(n_splats)
         cfg = _Config()
@@ -301,7 +301,19 @@ class Trainer:
         cfg.stream = stream
         self.stream = stream  # HIP stream handle the context works on; None: a stream the library owns
         h = C.c_void_p()
-        rc = self.L.s2d_create(C.byref(cfg), C.byref(h))
+        # chunk_pairs (tests): the (tile, splat) pair budget beyond which a scene is rendered by index ranges of the splats;
+        # the library reads S2D_CHUNK_PAIRS when the context is created (default 2^30)
+        old_env = os.environ.get("S2D_CHUNK_PAIRS")
+        if chunk_pairs is not None:
+            os.environ["S2D_CHUNK_PAIRS"] = str(int(chunk_pairs))
+        try:
+            rc = self.L.s2d_create(C.byref(cfg), C.byref(h))
+        finally:
+            if chunk_pairs is not None:
+                if old_env is None:
+                    del os.environ["S2D_CHUNK_PAIRS"]
+                else:
+                    os.environ["S2D_CHUNK_PAIRS"] = old_env
         self._h = h
         if rc != 0:
             msg = self.L.s2d_last_error(h).decode() if h else "s2d_create rejected the configuration"

@@ -12,6 +12,7 @@
 #include "../../include/splat2d_test.h"
 
 #include <algorithm>
+#include <vector>
 #include <climits>
 #include <cmath>
 #include <cstdarg>
@@ -68,6 +69,15 @@ struct s2d_ctx {
     uint32_t* d_tl_hist = nullptr;     // per (row, column, chunk) counts + scan workspace
     size_t tl_hist_capacity = 0;       // words
     uint32_t* d_list = nullptr; // == one of d_vals after the sort
+    // Index-range ("chunked") rendering: when the (tile, splat) pairs of a scene exceed chunk_pairs -- at the latest 2^32 - 65536,
+    // what 32-bit list positions can address -- the splats are cut into consecutive index ranges of at most that many
+    // pairs, and the lists of one range at a time are built and walked front to back (chunked_forward / chunked_backward)
+    uint64_t chunk_pairs = 1ull << 30;   // S2D_CHUNK_PAIRS overrides (tests force the path on small scenes)
+    std::vector<int> chunks;             // range k = splats [chunks[k], chunks[k+1]); empty: one set of lists
+    int chunks_used = 0;                 // ranges the last forward pass walked before every pixel was saturated
+    int chunk_built = -1;                // the range whose lists are in the buffers now
+    float4* d_state = nullptr;           // per pixel of the slab: (r, g, b, T) carried from range to range
+    uint32_t* d_chunk_alive = nullptr;   // != 0: some pixel is still above the throughput cut-off after this range
     uint64_t pairs = 0;
     uint64_t rebins = 0;
     bool lists_valid = false;
@@ -209,13 +219,21 @@ int ensure_tl_hist(s2d_ctx* c, uint64_t entries)
 // Two builders with the same result (every tile's list ascending in splat index): the two-level one of s2d_tilelists.hip
 // (images of up to kTlMaxColumns tile columns), and the generic one -- all (tile, splat) pairs emitted in splat order and
 // radix-sorted by tile -- for wider images and on request (S2D_CFG_GENERIC_BINNING).
-int rebuild_lists(s2d_ctx* c)
+// first / count: the index range of the splats to list (count < 0: all of them).  A range's lists hold indices RELATIVE to
+// its first splat -- every per-splat array is handed over from that splat on -- and so do the scanned offsets.
+// Returns kNeedChunks (and builds nothing) when all splats were asked for and their pairs exceed chunk_pairs.
+constexpr int kNeedChunks = -100;
+int rebuild_lists(s2d_ctx* c, int first = 0, int count = -1)
 {
-    const int n = c->n;
+    const bool whole = count < 0;
+    const int n = whole ? c->n : count;
+    const TileRect* const rects = c->d_rects + first;
+    const uint32_t *const counts = c->d_counts + first, *const row_counts = c->d_row_counts ? c->d_row_counts + first : nullptr;
+    uint32_t *const offsets = c->d_offsets + first, *const row_offsets = c->d_row_offsets ? c->d_row_offsets + first : nullptr;
     // the scans' last kernels store their totals into host-mapped memory themselves (no copy engine between two kernels)
-    S2D_HIP(c, exclusive_scan_u32(c->d_counts, c->d_offsets, n, c->d_scan_temp, c->d_total, c->stream, c->h_total));
+    S2D_HIP(c, exclusive_scan_u32(counts, offsets, n, c->d_scan_temp, c->d_total, c->stream, c->h_total));
     if (c->two_level)
-        S2D_HIP(c, exclusive_scan_u32(c->d_row_counts, c->d_row_offsets, n, c->d_scan_temp, c->d_total + 1, c->stream, c->h_total + 1));
+        S2D_HIP(c, exclusive_scan_u32(row_counts, row_offsets, n, c->d_scan_temp, c->d_total + 1, c->stream, c->h_total + 1));
     S2D_HIP(c, hipEventRecord(c->ev_total, c->stream));
     // The emission needs the offsets, not the totals (it never writes past the buffers' capacity): queue it behind the
     // scans and wait for the SCANS only, so the host reads the totals and queues the rest while the emission runs instead
@@ -223,16 +241,17 @@ int rebuild_lists(s2d_ctx* c)
     // (rare: they are sized with a quarter to spare) is the emission queued again.
     auto emit = [&]() -> hipError_t {
         if (c->two_level) // (there are never more entries than pairs: the pair buffers hold them)
-            return launch_emit_row_entries(c->d_rects, c->d_row_offsets, c->d_row_counts, n, c->d_keys[0], c->d_vals[0],
+            return launch_emit_row_entries(rects, row_offsets, row_counts, n, c->d_keys[0], c->d_vals[0],
                                            (uint32_t)c->pair_capacity, c->stream);
-        return launch_emit_pairs(c->d_rects, c->d_offsets, c->d_counts, n, c->g, c->d_keys[0], c->d_vals[0], (uint32_t)c->pair_capacity,
+        return launch_emit_pairs(rects, offsets, counts, n, c->g, c->d_keys[0], c->d_vals[0], (uint32_t)c->pair_capacity,
                                  c->stream);
     };
     S2D_HIP(c, emit());
     S2D_HIP(c, hipEventSynchronize(c->ev_total));
     const uint64_t total = *(volatile uint32_t*)c->h_total; // saturates at 0xFFFFFFFF instead of wrapping (scan_top_kernel)
+    if (whole && total > c->chunk_pairs) return kNeedChunks; // (the emission queued above wrote within the buffers' capacity: harmless)
     if (total >= 0xFFFF0000ull)
-        return fail(c, S2D_E_NOMEM, "tile lists need more than 2^32 - 65536 (tile, splat) pairs");
+        return fail(c, S2D_E_NOMEM, "the tile lists of splats %d..%d need more than 2^32 - 65536 (tile, splat) pairs", first, first + n - 1);
     if (total > c->pair_capacity) {
         int rc = ensure_pair_capacity(c, total);
         if (rc != S2D_OK) return rc;
@@ -279,8 +298,91 @@ int rebuild_lists(s2d_ctx* c)
     }
     c->pairs = total;
     c->rebins++;
-    c->lists_valid = true;
+    c->lists_valid = whole; // a range's lists are walked once and replaced by the next range's
     c->since_rebin = 0;
+    return S2D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Index-range ("chunked") rendering.  The reference's loops have no limit on the number of (pixel, splat) pairs
+// (main.cpp:492-536); 32-bit list positions have one, and long before it the list and mask buffers have a price.  A scene
+// beyond chunk_pairs is rendered range by range: cut where the running pair count would pass the budget, build the
+// lists of one range, walk them, carry the per-pixel (colour, T) to the next range.  Blend order is index order
+// (main.cpp:419), so the cut changes no operation: the framebuffer is bit for bit the unchunked one, and so is every
+// gradient term (the sums differ in the order the atomics arrive, as always).  Lists are rebuilt every pass: this is the
+// path for scenes that do not fit, not a fast one.
+// ---------------------------------------------------------------------------------------------------------------------
+int plan_chunks(s2d_ctx* c)
+{
+    std::vector<uint32_t> cnt((size_t)c->n);
+    S2D_HIP(c, hipMemcpyAsync(cnt.data(), c->d_counts, cnt.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    S2D_HIP(c, hipStreamSynchronize(c->stream));
+    c->chunks.assign(1, 0);
+    uint64_t acc = 0;
+    for (int i = 0; i < c->n; i++) {
+        if (acc > 0 && acc + cnt[(size_t)i] > c->chunk_pairs) {
+            c->chunks.push_back(i);
+            acc = 0;
+        }
+        acc += cnt[(size_t)i];
+    }
+    c->chunks.push_back(c->n);
+    if (!c->d_state) S2D_HIP(c, dev_alloc(&c->d_state, (size_t)c->g.W * (size_t)(c->g.row_end - c->g.row_begin)));
+    if (!c->d_chunk_alive) S2D_HIP(c, dev_alloc(&c->d_chunk_alive, 1));
+    return S2D_OK;
+}
+
+int build_chunk(s2d_ctx* c, int k)
+{
+    if (c->chunk_built == k) return S2D_OK;
+    c->chunk_built = -1;
+    if (int rc = rebuild_lists(c, c->chunks[(size_t)k], c->chunks[(size_t)k + 1] - c->chunks[(size_t)k])) return rc;
+    c->chunk_built = k;
+    return S2D_OK;
+}
+
+// Forward pass over the ranges (main.cpp:414-546); stops behind the range after which no pixel of the slab is above the
+// throughput cut-off any more (main.cpp:520: nothing later could change a pixel).
+int chunked_forward(s2d_ctx* c)
+{
+    const bool exact = (c->cfg.flags & S2D_CFG_EXACT_EXP) != 0;
+    const int K = (int)c->chunks.size() - 1;
+    c->chunks_used = 0;
+    c->chunk_built = -1;
+    for (int k = 0; k < K; k++) {
+        if (int rc = build_chunk(c, k)) return rc;
+        S2D_HIP(c, hipMemsetAsync(c->d_chunk_alive, 0, sizeof(uint32_t), c->stream));
+        S2D_HIP(c, launch_raster_forward_chunk(c->d_tile_off, c->d_list, c->d_proj + c->chunks[(size_t)k], c->d_image0, c->half_images,
+                                               c->d_state, k == 0, c->d_wave_masks, c->g, c->d_status, c->iterations,
+                                               c->d_chunk_alive, exact, c->stream));
+        c->chunks_used = k + 1;
+        if (k + 1 < K) {
+            S2D_HIP(c, hipMemcpyAsync(c->h_total + 2, c->d_chunk_alive, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            S2D_HIP(c, hipStreamSynchronize(c->stream));
+            if (*(volatile uint32_t*)(c->h_total + 2) == 0u) break;
+        }
+    }
+    return S2D_OK;
+}
+
+// Backward pass over the same ranges (main.cpp:548-712), from a fresh per-pixel state; image0 holds the final colours.
+int chunked_backward(s2d_ctx* c, bool need_opacity_grad)
+{
+    const bool exact = (c->cfg.flags & S2D_CFG_EXACT_EXP) != 0;
+    for (int k = 0; k < c->chunks_used; k++) {
+        if (int rc = build_chunk(c, k)) return rc;
+        const int first = c->chunks[(size_t)k], count = c->chunks[(size_t)k + 1] - first;
+        DetGather dg{};
+        if (c->deterministic) {
+            c->det_epoch++;
+            dg = DetGather{c->d_rects + first, c->d_offsets + first, c->d_counts + first, c->d_det_data, c->d_det_stamp,
+                           c->d_det_touched + first, c->det_epoch, count};
+        }
+        S2D_HIP(c, launch_raster_backward_chunk(c->d_tile_off, c->d_list, c->d_proj + first, c->d_image0, c->d_ref, c->half_images,
+                                                c->d_state, k == 0, c->d_wave_masks, c->d_grads + (size_t)first * 9, c->d_tile_sqerr,
+                                                c->g, need_opacity_grad, c->deterministic ? &dg : nullptr, c->d_status,
+                                                c->iterations, exact, c->stream));
+    }
     return S2D_OK;
 }
 
@@ -348,10 +450,27 @@ int queue_raster(s2d_ctx* c, const RasterJob& job)
     if (rebuild) {
         S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, c->margin, 0, c->d_proj, c->d_rects, c->d_counts,
                                   c->two_level ? c->d_row_counts : nullptr, c->d_status, 0, nullptr, c->stream));
-        if (int rc = rebuild_lists(c)) return rc;
+        c->chunks.clear();
+        int rc = rebuild_lists(c);
+        if (rc == kNeedChunks) {
+            // more pairs than one set of lists may hold: render by index ranges (every pass rebuilds: lists_valid stays false)
+            if (c->cfg.flags & S2D_CFG_COUNT_PAIRS)
+                return fail(c, S2D_E_NOMEM, "pair counting (S2D_CFG_COUNT_PAIRS) is not available for scenes beyond %llu (tile, splat) pairs",
+                            (unsigned long long)c->chunk_pairs);
+            c->lists_valid = false;
+            c->proj_fresh = true;
+            c->check_seq++;
+            if ((rc = plan_chunks(c)) != S2D_OK) return rc;
+            if ((rc = chunked_forward(c)) != S2D_OK) return rc;
+            if (job.fused && (rc = chunked_backward(c, job.need_opacity_grad)) != S2D_OK) return rc;
+            c->have_forward = true; // the forward pass over the ranges always stores image0
+            c->have_backward = false;
+            return S2D_OK;
+        }
+        if (rc != S2D_OK) return rc;
         c->proj_fresh = true;
         c->check_seq++; // the new lists cover the current parameters: a stamp that asked for them matches nothing now
-        if (int rc = launch_raster(c, false, job)) return rc;
+        if (int rc2 = launch_raster(c, false, job)) return rc2;
     }
     c->have_forward = !job.fused || job.write_image; // a fused launch told not to store image0 leaves an older frame there
     c->have_backward = false;
@@ -379,6 +498,10 @@ int queue_sqerr(s2d_ctx* c, bool defer = false)
 int queue_backward(s2d_ctx* c, bool need_opacity_grad)
 {
     if (!c->have_forward) return fail(c, S2D_E_STATE, "s2d_backward needs s2d_forward on the current parameters");
+    if (!c->chunks.empty()) { // the forward pass went over index ranges: so does this one
+        if (int rc = chunked_backward(c, need_opacity_grad)) return rc;
+        return queue_sqerr(c);
+    }
     DetGather dg{};
     if (c->deterministic) {
         c->det_epoch++; // a fresh stamp per backward pass (slots of earlier passes become invalid)
@@ -418,7 +541,7 @@ int queue_forward_backward(s2d_ctx* c, bool need_opacity_grad, bool write_image,
     // cheaper still: 535x426 / 50 k measured 6.9 % slower with the in-raster sum.)
     job.sum_sqerr = c->g.num_tiles <= kSqerrSmallTiles && (c->n + 255) / 256 < kSqerrChunks;
     if (int rc = queue_raster(c, job)) return rc;
-    if (job.sum_sqerr) { // nothing left to queue
+    if (job.sum_sqerr && c->chunks.empty()) { // nothing left to queue
         c->last_sqerr_slot = c->iterations % c->trace_cap;
         c->have_backward = true;
         c->sqerr_deferred = false;
@@ -570,6 +693,10 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, dev_alloc(&c->d_tile_off, (size_t)g.num_tiles + 1));
     S2D_HIP(c, dev_alloc(&c->d_tile_first, ((size_t)1 << key_bits_for(g.num_tiles)) + tile_first_temp_words(g.num_tiles))); // + chunk minima
     c->two_level = g.tiles_x <= kTlMaxColumns && !(cfg->flags & S2D_CFG_GENERIC_BINNING);
+    if (const char* e = getenv("S2D_CHUNK_PAIRS")) { // pairs per index range (tests; default 2^30, never beyond 32-bit positions)
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v > 0) c->chunk_pairs = std::min<unsigned long long>(v, 0xFFFF0000ull - 1);
+    }
     if (c->two_level) {
         S2D_HIP(c, dev_alloc(&c->d_row_counts, n));
         S2D_HIP(c, dev_alloc(&c->d_row_offsets, n));
@@ -625,7 +752,7 @@ void s2d_destroy(s2d_ctx* c)
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
                         c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_det_touched, c->d_tile_off, c->d_tile_first, c->d_row_counts, c->d_row_offsets, c->d_row_off,
                         c->d_chunk_base, c->d_tl_hist, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work, c->d_sqerr_trace,
-                        c->d_status, c->d_counters};
+                        c->d_status, c->d_counters, c->d_state, c->d_chunk_alive};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (c->ev_flag) (void)hipEventDestroy(c->ev_flag);
@@ -1144,12 +1271,3 @@ done:
 }
 
 } // extern "C"
-
-#ifdef S2D_EXP_CLOCK
-// diagnostic build only: the four s_memrealtime stamps per tile the fused raster kernel left behind the lane masks
-extern "C" int s2d_exp_read_probe(s2d_ctx* c, unsigned long long* out, int tiles)
-{
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return -1;
-    return hipMemcpy(out, c->d_wave_masks + (size_t)c->pairs * 4, (size_t)tiles * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
-}
-#endif

@@ -215,7 +215,18 @@ hipError_t launch_raster_fused(const uint32_t* tile_off, const uint32_t* list, c
                                double* tile_sqerr, Geometry g, bool need_opacity_grad, const DetGather* dg,
                                const DeviceStatus* status, int abort_stamp, int iteration, bool write_image, bool exact_exp,
                                SqerrJob sq, hipStream_t stream);
-// Sums tile_sqerr[0..num_tiles) in a fixed order into *out.
+// Index-range rendering (scenes beyond one set of lists; s2d_raster.hip "chunked", s2d_api.hip chunked_raster): the lists are
+// those of ONE index range of the splats (proj / grads / the DetGather arrays point at the range's first splat, list words
+// count from it); `state` carries (r, g, b, T) per pixel from range to range; first: start from (0, 0, 0, 1).
+hipError_t launch_raster_forward_chunk(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
+                                       bool half_images, float4* state, bool first, unsigned long long* wave_masks, Geometry g,
+                                       const DeviceStatus* status, int iteration, uint32_t* any_alive, bool exact_exp,
+                                       hipStream_t stream);
+hipError_t launch_raster_backward_chunk(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, const void* image0,
+                                        const void* image_ref, bool half_images, float4* state, bool first,
+                                        unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
+                                        bool need_opacity_grad, const DetGather* dg, const DeviceStatus* status, int iteration,
+                                        bool exact_exp, hipStream_t stream);
 // slab ownership (s2d_halo.hip): `held` == nullptr means every splat is held (single rank, or replicated state)
 hipError_t launch_halo_masks(const float* splats, const uint8_t* held, int n, int world, const int* row_bounds, float margin,
                              uint32_t* masks, hipStream_t stream);

@@ -206,21 +206,29 @@ __device__ __forceinline__ bool block_any_alive(int4* flags, int w, int lane, un
 
 // One tile's forward walk (main.cpp:419-536 for its pixels): leaves the final colour of this thread's pixel in
 // (crg, cb) and the lane masks of every staged pair in wave_masks.
-template <bool COUNT, bool EXACT>
+// CHUNK (scenes whose (tile, splat) pairs do not fit one set of lists, s2d_api.hip chunked_raster): the list holds the
+// splats of one INDEX RANGE only; the walk continues from the pixel's state after the ranges before it -- (crg, cb) and
+// *T_io on entry -- and leaves the state for the range after it.  The reference's loop is front to back in index order
+// (main.cpp:419), so cutting it at any index and carrying (colour, T) across the cut changes no operation.
+template <bool COUNT, bool EXACT, bool CHUNK = false>
 __device__ __forceinline__ void forward_tile(FwdShared& s, const TileCtx& c, const uint32_t* __restrict__ tile_off,
                                              const uint32_t* __restrict__ list, const ProjRec* __restrict__ proj,
                                              unsigned long long* __restrict__ wave_masks, const Geometry& g,
-                                             PairCounters* __restrict__ counters, f2& crg, float& cb)
+                                             PairCounters* __restrict__ counters, f2& crg, float& cb, float* T_io = nullptr)
 {
     const int tid = c.tid, lane = c.lane, w = c.w;
     const f2 pxy = c.pxy;
-    crg = mk2(0.0f, 0.0f);                                  // main.cpp:414: (0,0,0,1)
-    cb = 0.0f;
     float T = 1.0f;
+    if (CHUNK) {
+        T = *T_io;
+    } else {
+        crg = mk2(0.0f, 0.0f);                              // main.cpp:414: (0,0,0,1)
+        cb = 0.0f;
+    }
     // Pixels still above the throughput cut-off (main.cpp:520), as ONE wave-uniform 64-bit mask in scalar registers.
     // (A per-lane bool here costs ~15 scalar instructions per blended entry to merge with exec, and the CU's
     // single scalar unit -- not the SIMDs -- then bounds the loop; measured, profiles/r01/valu_rates.txt.)
-    unsigned long long alive_mask = __ballot(c.inside);
+    unsigned long long alive_mask = __ballot(CHUNK ? c.inside && !(T < kMinThroughput) : c.inside);
     unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0, n_rows_hit = 0, n_staged_hit = 0;
 
     const uint32_t beg = tile_off[c.tile], end = tile_off[c.tile + 1];
@@ -280,6 +288,7 @@ __device__ __forceinline__ void forward_tile(FwdShared& s, const TileCtx& c, con
         }
         if (!block_any_alive(&s.alive, w, lane, alive_mask)) break; // every pixel of the tile saturated: retire it
     }
+    if (CHUNK) *T_io = T;
     if (COUNT) {
         atomicAdd(&counters->fwd_visited, n_vis);
         atomicAdd(&counters->fwd_active, n_act);
@@ -471,14 +480,16 @@ struct BwdShared {
 
 // One tile's backward walk (main.cpp:552-711 for its pixels) from the pixel's final colour `fin` and target `ref`:
 // adds the tile's partial gradients into grads (or its deterministic slots) and stores the tile's squared error.
-template <bool COUNT, bool NEED_OP, bool DET, bool EXACT>
+// CHUNK: as in forward_tile -- the list is one index range of the splats, *state_io (running colour r, g, b and T of
+// main.cpp:601-625, :707) is the pixel's state after the ranges before it on entry and after this range on return.
+template <bool COUNT, bool NEED_OP, bool DET, bool EXACT, bool CHUNK = false>
 __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& c, const float4 fin, const float4 ref,
                                               const uint32_t* __restrict__ tile_off, const uint32_t* __restrict__ list,
                                               const ProjRec* __restrict__ proj,
                                               const unsigned long long* __restrict__ wave_masks,
                                               float* __restrict__ grads, double* __restrict__ tile_sqerr,
                                               const Geometry& g, const DetSlots& det, PairCounters* __restrict__ counters,
-                                              const SqerrJob& sq)
+                                              const SqerrJob& sq, float4* state_io = nullptr)
 {
     constexpr int BB = BwdShared<DET>::kBatch; // entries per staged batch
     const int tid = c.tid, lane = c.lane, w = c.w;
@@ -524,7 +535,12 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
 
     f2 crg = mk2(0.0f, 0.0f);                        // image1 = (0,0,0,1), main.cpp:549
     float cb = 0.0f, T = 1.0f;
-    unsigned long long alive_mask = __ballot(inside); // wave-uniform, scalar registers (see the forward kernel)
+    if (CHUNK) {
+        crg = mk2(state_io->x, state_io->y);
+        cb = state_io->z;
+        T = state_io->w;
+    }
+    unsigned long long alive_mask = __ballot(CHUNK ? inside && !(T < kMinThroughput) : inside); // wave-uniform, scalar registers (see the forward kernel)
     unsigned long long n_vis = 0, n_act = 0, n_staged = 0, n_exec = 0;
 
     const uint32_t beg = tile_off[c.tile], end = tile_off[c.tile + 1];
@@ -692,6 +708,7 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
         }
         if (!any) break;
     }
+    if (CHUNK) *state_io = make_float4(crg.x, crg.y, cb, T);
     if (COUNT) {
         atomicAdd(&counters->bwd_visited, n_vis);
         atomicAdd(&counters->bwd_active, n_act);
@@ -750,16 +767,9 @@ __global__ __launch_bounds__(256, 8) void raster_fused_kernel(const uint32_t* __
     const int tile = tile_of_block(blockIdx.x, g);
     if (tile < 0) return;
     const TileCtx c = tile_ctx(tile, g);
-#ifdef S2D_EXP_CLOCK
-    unsigned long long* const probe = wave_masks + (size_t)tile_off[g.num_tiles] * 4 + (size_t)tile * 4;
-    if (threadIdx.x == 0) probe[0] = __builtin_amdgcn_s_memrealtime();
-#endif
     f2 crg;
     float cb;
     forward_tile<false, EXACT>(*reinterpret_cast<FwdShared*>(smem), c, tile_off, list, proj, wave_masks, g, nullptr, crg, cb);
-#ifdef S2D_EXP_CLOCK
-    if (threadIdx.x == 0) probe[1] = __builtin_amdgcn_s_memrealtime();
-#endif
     float4 fin = make_float4(crg.x, crg.y, cb, 1.0f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
     if (HALF) { // what the backward pass would read back from the fp16 framebuffer
         const __half2 a = __floats2half2_rn(fin.x, fin.y), b = __floats2half2_rn(fin.z, fin.w);
@@ -775,12 +785,81 @@ __global__ __launch_bounds__(256, 8) void raster_fused_kernel(const uint32_t* __
     __syncthreads(); // the backward walk re-uses the LDS the forward walk's last flag exchange may still be reading
     backward_tile<false, NEED_OP, DET, EXACT>(*reinterpret_cast<BwdShared<DET>*>(smem), c, fin, ref, tile_off, list, proj,
                                               wave_masks, grads, tile_sqerr, g, det, nullptr, sq);
-#ifdef S2D_EXP_CLOCK
-    if (threadIdx.x == 0) probe[2] = __builtin_amdgcn_s_memrealtime();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) probe[3] = __builtin_amdgcn_s_memrealtime();
-#endif
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Index-range ("chunked") rendering, for scenes with more (tile, splat) pairs than one set of lists may hold
+// (s2d_api.hip chunked_raster).  The splats are cut into consecutive index ranges; the lists of one range at a time are
+// built and walked, front to back like the reference's loops (main.cpp:419, :552), and the per-pixel state is carried
+// from range to range in `state` (fp32 whatever the image format): (r, g, b, T).
+//   forward pass : raster_forward_chunk_kernel per range; each stores the state and image0 (.w = 1, main.cpp:543-546),
+//                  so image0 is final after the last range -- or after the range behind which no pixel is alive any
+//                  more (*any_alive stays 0: the host skips the ranges that follow, in both passes).
+//   backward pass: raster_backward_chunk_kernel per range, from a fresh state: the forward walk of the range (only for its
+//                  lane masks -- the backward walk reads them back, exactly as in the fused kernel) and the backward
+//                  walk from the same state, with the FINAL colours of the forward pass out of image0.
+// ---------------------------------------------------------------------------------------------------
+template <bool HALF, bool EXACT>
+__global__ __launch_bounds__(256) void raster_forward_chunk_kernel(const uint32_t* __restrict__ tile_off,
+                                                                   const uint32_t* __restrict__ list,
+                                                                   const ProjRec* __restrict__ proj, void* __restrict__ image0,
+                                                                   float4* __restrict__ state, int first,
+                                                                   unsigned long long* __restrict__ wave_masks, Geometry g,
+                                                                   const DeviceStatus* __restrict__ status, int iteration,
+                                                                   uint32_t* __restrict__ any_alive)
+{
+    __shared__ FwdShared s;
+    if (launch_is_void(status, 0, iteration)) return;
+    const int tile = tile_of_block(blockIdx.x, g);
+    if (tile < 0) return;
+    const TileCtx c = tile_ctx(tile, g);
+    float4 st = make_float4(0.0f, 0.0f, 0.0f, 1.0f); // main.cpp:414
+    if (!first && c.inside) st = state[pixel_index(c, g)];
+    f2 crg = mk2(st.x, st.y);
+    float cb = st.z, T = st.w;
+    forward_tile<false, EXACT, true>(s, c, tile_off, list, proj, wave_masks, g, nullptr, crg, cb, &T);
+    if (c.inside) {
+        state[pixel_index(c, g)] = make_float4(crg.x, crg.y, cb, T);
+        store_pixel<HALF>(image0, pixel_index(c, g), make_float4(crg.x, crg.y, cb, 1.0f)); // .w reset, main.cpp:543-546
+    }
+    if (__ballot(c.inside && !(T < kMinThroughput)) != 0ull && c.lane == 0) atomicOr(any_alive, 1u);
+}
+
+template <bool NEED_OP, bool HALF, bool DET, bool EXACT>
+__global__ __launch_bounds__(256) void raster_backward_chunk_kernel(const uint32_t* __restrict__ tile_off,
+                                                                    const uint32_t* __restrict__ list,
+                                                                    const ProjRec* __restrict__ proj,
+                                                                    const void* __restrict__ image0,
+                                                                    const void* __restrict__ image_ref,
+                                                                    float4* __restrict__ state, int first,
+                                                                    unsigned long long* __restrict__ wave_masks,
+                                                                    float* __restrict__ grads, double* __restrict__ tile_sqerr,
+                                                                    Geometry g, DetSlots det,
+                                                                    const DeviceStatus* __restrict__ status, int iteration)
+{
+    constexpr size_t kBytes = sizeof(BwdShared<DET>) > sizeof(FwdShared) ? sizeof(BwdShared<DET>) : sizeof(FwdShared);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kBytes];
+    if (launch_is_void(status, 0, iteration)) return;
+    const int tile = tile_of_block(blockIdx.x, g);
+    if (tile < 0) return;
+    const TileCtx c = tile_ctx(tile, g);
+    float4 st = make_float4(0.0f, 0.0f, 0.0f, 1.0f); // image1 = (0,0,0,1), main.cpp:549
+    float4 fin = make_float4(0.f, 0.f, 0.f, 0.f), ref = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c.inside) {
+        if (!first) st = state[pixel_index(c, g)];
+        fin = load_pixel<HALF>(image0, pixel_index(c, g));    // finalColor, main.cpp:613: of ALL ranges
+        ref = load_pixel<HALF>(image_ref, pixel_index(c, g));
+    }
+    {   // the lane masks of this range's batches, from the state the backward walk starts from (results discarded)
+        f2 crg = mk2(st.x, st.y);
+        float cb = st.z, T = st.w;
+        forward_tile<false, EXACT, true>(*reinterpret_cast<FwdShared*>(smem), c, tile_off, list, proj, wave_masks, g, nullptr, crg, cb, &T);
+    }
+    __syncthreads(); // the backward walk re-uses the LDS the forward walk's last flag exchange may still be reading
+    backward_tile<false, NEED_OP, DET, EXACT, true>(*reinterpret_cast<BwdShared<DET>*>(smem), c, fin, ref, tile_off, list, proj,
+                                                    wave_masks, grads, tile_sqerr, g, det, nullptr,
+                                                    SqerrJob{nullptr, 0, nullptr, nullptr}, &st);
+    if (c.inside) state[pixel_index(c, g)] = st;
 }
 
 // Deterministic mode: gradient of splat i = sum of the partials its tiles stored this iteration, in emission
@@ -943,6 +1022,53 @@ hipError_t launch_raster_fused(const uint32_t* tile_off, const uint32_t* list, c
     }
 #undef S2D_LAUNCH_FUSED_D
 #undef S2D_LAUNCH_FUSED
+    if (dg && dg->n > 0)
+        hipLaunchKernelGGL(gather_grads_kernel, dim3((dg->n + 255) / 256), dim3(256), 0, stream, dg->offsets, dg->counts,
+                           dg->n, dg->data, dg->stamp, dg->touched, dg->now, grads);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster_forward_chunk(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, void* image0,
+                                       bool half_images, float4* state, bool first, unsigned long long* wave_masks, Geometry g,
+                                       const DeviceStatus* status, int iteration, uint32_t* any_alive, bool exact_exp,
+                                       hipStream_t stream)
+{
+    if (g.num_tiles <= 0) return hipSuccess;
+    const dim3 grid(raster_grid(g.num_tiles)), block(256);
+    const int f = first ? 1 : 0;
+#define S2D_LAUNCH_FC(H, X) \
+    hipLaunchKernelGGL((raster_forward_chunk_kernel<H, X>), grid, block, 0, stream, tile_off, list, proj, image0, state, f, wave_masks, g, status, iteration, any_alive)
+    if (exact_exp) S2D_LAUNCH_FC(false, true);
+    else if (half_images) S2D_LAUNCH_FC(true, false);
+    else S2D_LAUNCH_FC(false, false);
+#undef S2D_LAUNCH_FC
+    return hipGetLastError();
+}
+
+hipError_t launch_raster_backward_chunk(const uint32_t* tile_off, const uint32_t* list, const ProjRec* proj, const void* image0,
+                                        const void* image_ref, bool half_images, float4* state, bool first,
+                                        unsigned long long* wave_masks, float* grads, double* tile_sqerr, Geometry g,
+                                        bool need_opacity_grad, const DetGather* dg, const DeviceStatus* status, int iteration,
+                                        bool exact_exp, hipStream_t stream)
+{
+    if (g.num_tiles <= 0) return hipSuccess;
+    DetSlots det{nullptr, nullptr, nullptr, nullptr, nullptr, 0u};
+    if (dg) det = DetSlots{dg->rects, dg->offsets, dg->data, dg->stamp, dg->touched, dg->now};
+    const dim3 grid(raster_grid(g.num_tiles)), block(256);
+    const int f = first ? 1 : 0;
+#define S2D_LAUNCH_BC(O, H, D, X)                                                                                              \
+    hipLaunchKernelGGL((raster_backward_chunk_kernel<O, H, D, X>), grid, block, 0, stream, tile_off, list, proj, image0, image_ref, \
+                       state, f, wave_masks, grads, tile_sqerr, g, det, status, iteration)
+#define S2D_LAUNCH_BC_D(O, H, X) do { if (dg) S2D_LAUNCH_BC(O, H, true, X); else S2D_LAUNCH_BC(O, H, false, X); } while (0)
+    if (exact_exp) {
+        if (need_opacity_grad) S2D_LAUNCH_BC_D(true, false, true); else S2D_LAUNCH_BC_D(false, false, true);
+    } else if (half_images) {
+        if (need_opacity_grad) S2D_LAUNCH_BC_D(true, true, false); else S2D_LAUNCH_BC_D(false, true, false);
+    } else {
+        if (need_opacity_grad) S2D_LAUNCH_BC_D(true, false, false); else S2D_LAUNCH_BC_D(false, false, false);
+    }
+#undef S2D_LAUNCH_BC_D
+#undef S2D_LAUNCH_BC
     if (dg && dg->n > 0)
         hipLaunchKernelGGL(gather_grads_kernel, dim3((dg->n + 255) / 256), dim3(256), 0, stream, dg->offsets, dg->counts,
                            dg->n, dg->data, dg->stamp, dg->touched, dg->now, grads);

@@ -387,24 +387,47 @@ def test_cfg5_8192_4m_fp16_window_matches_oracle_on_rounded_images():
     assert len(li) > 1500
 
 
-def test_pair_count_beyond_32_bits_is_reported_not_wrapped():
-    """70 000 splats at the sx/sy clamp cover all 65 536 tiles of a 4096^2 image each: 4.6e9 (tile, splat) pairs.  The
-    32-bit scan saturates instead of wrapping to a small number, and the forward pass fails with S2D_E_NOMEM rather
-    than rendering from truncated lists."""
-    n = 70_000
+def test_pair_count_beyond_32_bits_renders_by_index_ranges():
+    """70 000 splats at the sx/sy clamp (main.cpp:744-745) cover all 65 536 tiles of a 4096^2 image each: 4.6e9 (tile, splat)
+    pairs, more than 32-bit list positions can address -- and a scene the reference's loops (main.cpp:492-536) run like any
+    other.  The 32-bit scan saturates instead of wrapping, and the library renders the scene by index ranges of the
+    splats (2^30 pairs = 16 384 splats per range), front to back, stopping behind the range after which every pixel is
+    below the throughput cut-off (main.cpp:520).  Nothing behind that point can change a pixel, so the frame must equal,
+    bit for bit, the frame of the first 5 000 splats alone rendered from one set of lists; the gradients of those splats
+    meet the usual bars between the two, and the splats behind the cut-off get exactly zero."""
+    n, head = 70_000, 5_000
     s = np.zeros(n, dtype=S2D.SPLAT_DTYPE)
-    s["pos"] = 2048.0
+    rng = np.random.default_rng(3)
+    s["pos"] = 2048.0 + rng.uniform(-20, 20, (n, 2)).astype(np.float32)
     s["sx"] = s["sy"] = 1024.0
-    s["color"] = 0.5
+    s["rot"] = rng.uniform(0, 3, n)
+    s["color"] = rng.uniform(0, 1, (n, 3))
     s["opacity"] = 0.5
+    with S2D.Trainer(4096, 4096, head) as t:
+        t.set_target_synthetic()
+        t.set_splats(s[:head])
+        t.forward()
+        want = t.get_image()
+        t.backward()
+        want_g = t.get_grads().view(np.float32).reshape(-1, 9).astype(np.float64)
+        assert t.stats()["pairs_binned"] == head * 65536
+    assert want[..., :3].max() > 0.2
     with S2D.Trainer(4096, 4096, n) as t:
         t.set_target_synthetic()
         t.set_splats(s)
-        with pytest.raises(S2D.S2DError) as ei:
-            t.forward()
-        assert ei.value.code == 4   # S2D_E_NOMEM
+        t.forward()
+        got = t.get_image()
+        t.backward()
+        g = t.get_grads().view(np.float32).reshape(-1, 9).astype(np.float64)
+        assert got.tobytes() == want.tobytes()
+        assert np.isfinite(g).all() and (g[head:] == 0).all()        # every pixel was saturated before splat 5 000
+        scale = np.abs(want_g).max(axis=0)
+        assert (np.abs(g[:head] - want_g) <= 1e-4 * scale).all()     # same terms, float-atomic order
+        # ... and the scene trains (iterations through the fused entry point)
+        tr = t.step(2)
+        assert np.isfinite(tr).all() and tr[1] < tr[0]
         s["sx"][1000:] = 2.0
         s["sy"][1000:] = 2.0
-        t.set_splats(s)             # 1 000 image-covering splats still fit
+        t.set_splats(s)             # back under the budget: one set of lists again
         t.forward()
-        assert np.isfinite(t.get_image()).all()
+        assert np.isfinite(t.get_image()).all() and t.stats()["pairs_binned"] < 2 ** 30

@@ -617,6 +617,99 @@ def test_image_covering_splats_grow_the_pair_buffers():
     assert st["pairs_capacity"] >= st["pairs_binned"]
 
 
+@pytest.mark.parametrize("budget,kw", [(3000, {}), (700, {}), (3000, {"fp16_images": True}), (2500, {"generic_binning": True}),
+                                       (3000, {"row_begin": 64, "row_end": 160})])
+def test_index_range_rendering_equals_one_set_of_lists(budget, kw):
+    """Scenes whose (tile, splat) pairs exceed the pair budget are rendered by index ranges of the splats (front to back,
+    like main.cpp:419 / :552, with the per-pixel colour and T carried from range to range).  Forced here on the mini
+    scene with a budget of a few thousand pairs (default 2^30): the framebuffer must be the unchunked one bit for bit --
+    the cut changes no operation -- deterministic gradients too (a splat's partial sums all lie in its own range), the
+    gradients meet the oracle's bars, and whole training iterations give the same trace and parameters."""
+    tgt = mini_target()
+    n = 2000
+    o = O.OracleTrainer(tgt, n)
+    for _ in range(3):
+        o.step()
+    res = {}
+    for chunked in (False, True):
+        with S2D.Trainer(268, 213, n, deterministic=True, chunk_pairs=budget if chunked else None, **kw) as t:
+            t.set_target(tgt)
+            t.set_splats(o.splats.view(S2D.SPLAT_DTYPE))
+            t.set_adam(o.adams.view(S2D.ADAM_DTYPE), o.beta1t[0], o.beta2t[0], o.iterations)
+            t.forward()
+            img = t.get_image()
+            t.backward()
+            g = t.get_grads()
+            mse = t.mse()
+            t.adam_step()
+            tr = t.step(4)                       # fused forward + backward launches
+            t.forward_backward()
+            g2 = t.get_grads()
+            t.adam_step()
+            res[chunked] = (img.tobytes(), g.tobytes(), mse, tr.tobytes(), g2.tobytes(), t.get_splats().tobytes(), t.stats()["rebins"])
+            if chunked and not kw:
+                want = o.forward()
+                assert img.tobytes() == want.tobytes()
+                grad_check(g, o)
+    for k, name in enumerate(["image", "gradients", "mse", "trace of s2d_step", "gradients of s2d_forward_backward", "splats"]):
+        assert res[False][k] == res[True][k], name
+    assert res[True][6] > 4 * res[False][6]      # the ranges really were built one after the other
+
+
+def test_index_range_rendering_with_atomic_gradients_and_opacity():
+    """The same with the default float-atomic gradient sums and "Optimize opacity" on: bars against the oracle."""
+    tgt = mini_target()
+    o, t = make_pair(tgt, 1500, steps=2, opacity=True, chunk_pairs=2000)
+    with t:
+        t.forward()
+        assert t.get_image().tobytes() == o.forward().tobytes()
+        t.backward()
+        grad_check(t.get_grads(), o)
+        t.adam_step()
+        assert o.adam() == 0
+        st, want = o.step()
+        got = t.step(1)[0]
+        assert st == 0 and abs(got - want) <= 2e-5 * want
+
+
+@pytest.mark.parametrize("W,H,n,seed", [(8208, 64, 4000, 31), (16400, 40, 3000, 32)])
+def test_images_wider_than_512_tile_columns(W, H, n, seed):
+    """Beyond 8192 pixels of width (512 tile columns) the two-level list builder does not apply (its row entries carry
+    nine-bit column ranges, csrc/s2d_tilelists.hip) and the library takes the generic one -- all (tile, splat) pairs
+    radix-sorted by tile.  Same bars as everywhere: framebuffer bit-exact against the oracle, gradients within the three
+    bars, on splats that span from one tile to the whole width; and a training step follows the oracle's."""
+    s = random_splats(n, W, H, seed)
+    tgt = O.synthetic_target(W, H)
+    o = O.OracleTrainer(tgt, n)
+    o.splats[:] = s
+    want = o.forward().copy()
+    with S2D.Trainer(W, H, n) as t:
+        t.set_target(tgt)
+        t.set_splats(s)
+        t.forward()
+        assert t.get_image().tobytes() == want.tobytes()
+        t.backward()
+        g = t.get_grads()
+        assert t.stats()["pairs_binned"] > n
+    # Splats of up to 1024 px on a strip this wide sum ~1e5 terms per scalar, and the ORACLE's sequential fp32 sum is itself
+    # b_ref * sum|terms| away from the exact sum of those terms: bar (c), which is taken against the oracle's fp32 value with
+    # a floor of 0.02 * sum|terms|, is granted that much (50 * b_ref); bars (a) and (b) -- the GPU against the EXACT sum, and
+    # no further from it than the reference -- hold as everywhere.
+    w32, dsum, dabs = o.backward_stats()
+    nz = dabs > 0
+    b_ref = float((np.abs(w32.view(np.float32).reshape(-1, 9).astype(np.float64) - dsum)[nz] / dabs[nz]).max())
+    bars = O.grad_bars(g.view(np.float32), w32.view(np.float32), dsum, dabs, max(REL, 50.0 * b_ref))
+    assert bars["a_gpu_vs_exact"] <= 1e-6 and bars["c_gpu_vs_oracle"] <= 3e-4, bars
+    o = O.OracleTrainer(tgt, n)
+    o.splats[:] = s
+    with S2D.Trainer(W, H, n) as t:
+        t.set_target(tgt)
+        t.set_splats(s)
+        got = t.step(3)
+    want = [o.step()[1] for _ in range(3)]
+    np.testing.assert_allclose(got, want, rtol=2e-5)
+
+
 def test_low_opacity_deep_stacks():
     """opacity 0.1: ~50 splats contribute to every pixel before the 1/256 cut-off; gradients of deep stacks."""
     W, H, n = 160, 120, 3000
