@@ -38,8 +38,8 @@ constexpr int kOverlayVertices = 46; // per splat: 2 axes + 17 ellipse segments 
 // The vertex list of main.cpp:419-477 for one splat, in the reference's call order and with its arithmetic: cov_of
 // (:206-221), eignValues (:188-196), the inverse (:432-436), eigen_vectors_of_cov (:223-234; glm::normalize(v) =
 // v * (1 / sqrt(dot(v, v)))), the axes (:443-451), the 16-gon (:454-462; pr::CircleGenerator = the angle-addition
-// recurrence from (sin, cos) = (0, 1)), the box (:464-477).  tests/test_host_io_cpu.py compares these bit for bit with
-// the oracle's restatement (oracle/s2d_oracle.c s2do_overlay_vertices).
+// recurrence from (sin, cos) = (0, 1)), the box (:464-477).  tests/test_shared_math_host.py compares these bit for bit with
+// the test oracle's restatement of the same lines.
 inline void overlay_vertices(const s2d_splat& s, OverlayVertex* out)
 {
     struct V3 {
