@@ -265,7 +265,7 @@ struct s2d_multi {
     std::vector<std::string> rank_msg; // failures of this file's own HIP calls (the contexts keep theirs)
     std::vector<std::vector<double>> sqerr; // [rank][iteration of the call]: partial squared errors
     int iterations = 0;
-    char err[512] = {0};
+    char err[1280] = {0};
 };
 
 namespace {
@@ -281,7 +281,7 @@ int mfail(s2d_multi* m, int code, const char* fmt, ...)
 
 int rank_fail(s2d_multi* m, int rank, int code, const char* fmt, ...)
 {
-    char buf[400];
+    char buf[1024];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
@@ -313,6 +313,31 @@ inline void at_phase(s2d_multi* m, int rank, int phase, int iteration)
     P.ticks.fetch_add(1, std::memory_order_release);
 }
 
+// Where every rank's thread was last seen, for the reports below; and the rank furthest behind -- when a wait runs out
+// because of a rank that stopped answering, that is the one (the waiting ranks are iterations ahead of it, or at the same
+// iteration in a later phase).
+std::string phase_table(s2d_multi* m)
+{
+    std::string out;
+    int worst = 0;
+    long long worst_key = -1;
+    for (int q = 0; q < m->world; q++) {
+        const Progress& P = m->progress[(size_t)q];
+        const int ph = P.phase.load(), it = P.iteration.load();
+        char one[96];
+        snprintf(one, sizeof(one), "%srank %d: %s, iteration %d", out.empty() ? "" : "; ", q, phase_name(ph), it);
+        out += one;
+        const long long key = ph == PH_DONE ? (1LL << 60) : (long long)it * 16 + ph;
+        if (worst_key < 0 || key < worst_key) {
+            worst_key = key;
+            worst = q;
+        }
+    }
+    char tail[64];
+    snprintf(tail, sizeof(tail), "; furthest behind: rank %d (device %d)", worst, m->devices[(size_t)worst]);
+    return out + tail;
+}
+
 // This rank's communicator, taken out of its slot and aborted (RCCL then ends the kernels of this rank that wait for a
 // peer which will never arrive).  Whoever empties the slot owns the communicator: no second abort, no destroy afterwards.
 void abort_own_collective(s2d_multi* m, int rank)
@@ -334,11 +359,14 @@ void stop_everybody(s2d_multi* m, int rank)
     abort_own_collective(m, rank);
 }
 
-// Called by a rank thread inside its waits: has somebody failed?  Then this rank gives up its communicator too.
+// Called by a rank thread inside its waits: has somebody stopped the command?  If collectives were declared lost
+// (stop_everybody: a rank failed on the way or stopped answering) this rank gives up its communicator too.  A broken
+// barrier alone does not mean that: the finite guard (main.cpp:752-785) breaks it at the END of a rank's share, with every
+// collective of the call queued by everybody, and the handle stays usable.
 inline bool stopped(s2d_multi* m, int rank)
 {
     if (!m->barrier.broken.load(std::memory_order_acquire)) return false;
-    abort_own_collective(m, rank);
+    if (m->comms_aborted.load()) abort_own_collective(m, rank);
     return true;
 }
 
@@ -356,13 +384,7 @@ int meet_rank(s2d_multi* m, int r, const char* where)
     m->barrier.wait();
     if (!m->barrier.broken) return S2D_OK;
     if (m->barrier.timed_out.exchange(false)) {
-        std::string missing;
-        for (int q = 0; q < m->world; q++) {
-            const Progress& P = m->progress[(size_t)q];
-            char one[96];
-            snprintf(one, sizeof(one), "%srank %d: %s, iteration %d", missing.empty() ? "" : "; ", q, phase_name(P.phase.load()), P.iteration.load());
-            missing += one;
-        }
+        const std::string missing = phase_table(m);
         m->timed_out.store(true);
         stop_everybody(m, r);
         return rank_fail(m, r, S2D_E_STATE, "a rank did not reach the rendezvous of the %s within %d ms (%s)", where,
@@ -389,10 +411,12 @@ int wait_event(s2d_multi* m, int r, hipEvent_t ev, const char* what)
         if (limit > 0 && waited > (aborted ? 2LL * limit : (long long)limit)) {
             if (aborted) return kStopped; // somebody else already reports; this stream is left as it is
             const Progress& P = m->progress[(size_t)r];
+            const std::string table = phase_table(m);
             m->timed_out.store(true);
             stop_everybody(m, r);
             return rank_fail(m, r, S2D_E_STATE, "rank %d (device %d): the device did not finish the work queued on its stream within %d ms "
-                                                "while %s (iteration %d)", r, m->devices[(size_t)r], limit, what, P.iteration.load());
+                                                "while %s (iteration %d) -- its own kernels, or a collective / peer wait for a rank that "
+                                                "stopped answering (%s)", r, m->devices[(size_t)r], limit, what, P.iteration.load(), table.c_str());
         }
         if (spins < 2000) std::this_thread::yield();
         else std::this_thread::sleep_for(std::chrono::microseconds(spins < 20000 ? 20 : 200));
