@@ -100,6 +100,17 @@ struct s2d_ctx {
     uint32_t* d_held_ids = nullptr;   // ... and their ascending id list, *d_held_count long, for the Adam kernel
     uint32_t* d_held_count = nullptr;
     uint32_t* d_held_work = nullptr;  // n words of scan workspace
+    // Compact held state: with slab ownership the Adam step touches only the splats the rank holds -- a seventh of them at
+    // eight ranks, scattered through the id-indexed arrays (36- and 72-byte records, a cache line or two each).  Their
+    // parameters and moments are therefore kept in compact arrays in the order of d_held_ids, which the Adam kernel reads
+    // and writes in whole lines; the id-indexed arrays are brought up to date (compact_flush) before anything else reads
+    // them -- a projection pass, a hold-set refresh, a row transfer, a read-back -- and the compact copy is made afresh
+    // (compact_load) whenever the held set or the id-indexed arrays change from outside.
+    float* d_csplats = nullptr;  // n * 9 (capacity: every splat)
+    float* d_cadams = nullptr;   // n * 18
+    bool compact_live = false;   // the compact arrays mirror the held splats
+    bool compact_dirty = false;  // ... and are ahead of the id-indexed arrays (Adam steps since the last flush)
+    bool compact_enabled = true; // S2D_COMPACT_HELD=0 turns it off (A/B)
     uint8_t* d_held = nullptr; // slab ownership: 1 = this rank holds (updates) the splat; nullptr = all (s2d_halo_commit)
     double* d_sqerr_trace = nullptr;
     int trace_cap = 1 << 16;
@@ -420,6 +431,32 @@ int launch_raster(s2d_ctx* c, bool optimistic, const RasterJob& job)
     return S2D_OK;
 }
 
+// Compact held state (see s2d_ctx): bring the id-indexed parameter / moment arrays up to date ...
+int compact_flush(s2d_ctx* c)
+{
+    if (!c->compact_live || !c->compact_dirty) return S2D_OK;
+    S2D_HIP(c, launch_compact_copy(c->d_splats, 9, c->d_held_ids, c->d_held_count, c->n, c->d_csplats, false, c->stream));
+    S2D_HIP(c, launch_compact_copy(c->d_adams, 18, c->d_held_ids, c->d_held_count, c->n, c->d_cadams, false, c->stream));
+    c->compact_dirty = false;
+    return S2D_OK;
+}
+
+// ... and make the compact copy afresh from them (the held set, or the arrays, changed from outside).
+int compact_load(s2d_ctx* c)
+{
+    c->compact_live = false;
+    c->compact_dirty = false;
+    if (!c->d_held || !c->compact_enabled || c->n <= 0) return S2D_OK;
+    if (!c->d_csplats) {
+        S2D_HIP(c, dev_alloc(&c->d_csplats, (size_t)c->n * 9));
+        S2D_HIP(c, dev_alloc(&c->d_cadams, (size_t)c->n * 18));
+    }
+    S2D_HIP(c, launch_compact_copy(c->d_splats, 9, c->d_held_ids, c->d_held_count, c->n, c->d_csplats, true, c->stream));
+    S2D_HIP(c, launch_compact_copy(c->d_adams, 18, c->d_held_ids, c->d_held_count, c->n, c->d_cadams, true, c->stream));
+    c->compact_live = true;
+    return S2D_OK;
+}
+
 // Project the splats, make sure the tile lists cover them, run the forward raster (or the fused forward + backward).
 //
 // Steady state (lists re-used): the projection of the current parameters and the containment check were produced by
@@ -437,6 +474,7 @@ int queue_raster(s2d_ctx* c, const RasterJob& job)
     bool rebuild = scheduled;
     if (!scheduled) {
         if (!c->proj_fresh) { // parameters changed without a fused projection: project + check now
+            if (int rc = compact_flush(c)) return rc;
             c->check_seq++;
             S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, 0.0f, 1, c->d_proj, c->d_rects, c->d_counts, nullptr, c->d_status,
                                       c->check_seq, c->h_rebin_stamp, c->stream));
@@ -448,6 +486,7 @@ int queue_raster(s2d_ctx* c, const RasterJob& job)
         rebuild = *(volatile int*)c->h_rebin_stamp == c->check_seq;
     }
     if (rebuild) {
+        if (int rc = compact_flush(c)) return rc;
         S2D_HIP(c, launch_project(c->d_splats, c->d_held, c->n, c->g, c->margin, 0, c->d_proj, c->d_rects, c->d_counts,
                                   c->two_level ? c->d_row_counts : nullptr, c->d_status, 0, nullptr, c->stream));
         c->chunks.clear();
@@ -558,7 +597,9 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
     // rectangles (what the next forward needs), which saves a pass over the parameters per iteration.
     const bool fuse = c->lists_valid && c->rebin_interval > 1;
     if (fuse) c->check_seq++;
-    S2D_HIP(c, launch_adam(c->d_splats, c->d_adams, c->d_grads, c->d_held_ids, c->d_held_count, c->n, c->g, c->beta1t, c->beta2t,
+    const bool compact = c->compact_live && c->d_held_ids != nullptr;
+    S2D_HIP(c, launch_adam(compact ? c->d_csplats : c->d_splats, compact ? c->d_cadams : c->d_adams, c->d_grads, c->d_held_ids,
+                           c->d_held_count, c->n, c->g, c->beta1t, c->beta2t,
                            c->lr,
                            ((flags & S2D_STEP_OPTIMIZE_OPACITY) ? 1 : 0) | ((c->cfg.flags & S2D_CFG_ADAM_FP32) ? 2 : 0),
                            c->iterations, c->d_status,
@@ -566,7 +607,8 @@ int queue_adam(s2d_ctx* c, uint32_t flags)
                            c->sqerr_deferred ? SqerrJob{c->d_tile_sqerr, c->g.num_tiles, c->d_sqerr_trace + c->last_sqerr_slot,
                                                         c->d_tile_sqerr + c->g.num_tiles}
                                              : SqerrJob{nullptr, 0, nullptr, nullptr},
-                           c->stream));
+                           compact, c->stream));
+    if (compact) c->compact_dirty = true;
     c->sqerr_deferred = false;
     if (fuse) S2D_HIP(c, hipEventRecord(c->ev_flag, c->stream));
     c->proj_fresh = fuse;
@@ -693,6 +735,7 @@ int s2d_create(const s2d_config* cfg, s2d_ctx** out)
     S2D_HIP(c, dev_alloc(&c->d_tile_off, (size_t)g.num_tiles + 1));
     S2D_HIP(c, dev_alloc(&c->d_tile_first, ((size_t)1 << key_bits_for(g.num_tiles)) + tile_first_temp_words(g.num_tiles))); // + chunk minima
     c->two_level = g.tiles_x <= kTlMaxColumns && !(cfg->flags & S2D_CFG_GENERIC_BINNING);
+    if (const char* e = getenv("S2D_COMPACT_HELD")) c->compact_enabled = atoi(e) != 0;
     if (const char* e = getenv("S2D_CHUNK_PAIRS")) { // pairs per index range (tests; default 2^30, never beyond 32-bit positions)
         const unsigned long long v = strtoull(e, nullptr, 10);
         if (v > 0) c->chunk_pairs = std::min<unsigned long long>(v, 0xFFFF0000ull - 1);
@@ -752,7 +795,7 @@ void s2d_destroy(s2d_ctx* c)
                         c->d_scan_temp, c->d_total, c->d_keys[0], c->d_keys[1], c->d_vals[0], c->d_vals[1],
                         c->d_sort_temp, c->d_wave_masks, c->d_det_data, c->d_det_stamp, c->d_det_touched, c->d_tile_off, c->d_tile_first, c->d_row_counts, c->d_row_offsets, c->d_row_off,
                         c->d_chunk_base, c->d_tl_hist, c->d_image0, c->d_ref, c->d_tile_sqerr, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work, c->d_sqerr_trace,
-                        c->d_status, c->d_counters, c->d_state, c->d_chunk_alive};
+                        c->d_status, c->d_counters, c->d_state, c->d_chunk_alive, c->d_csplats, c->d_cadams};
         for (void* p : ptrs)
             if (p) (void)hipFree(p);
         if (c->ev_flag) (void)hipEventDestroy(c->ev_flag);
@@ -808,6 +851,7 @@ int s2d_init_splats(s2d_ctx* c)
     if (int rc = use_device(c)) return rc;
     if (int rc = flush_sqerr(c)) return rc;
     S2D_HIP(c, launch_init_splats(c->d_splats, c->d_adams, c->n, c->g.W, c->g.H, c->stream));
+    if (int rc = compact_load(c)) return rc; // (every record is new: nothing of the old compact copy is worth flushing)
     if (int rc = clear_dormant(c)) return rc;
     if (c->n > 0) S2D_HIP(c, hipMemsetAsync(c->d_grads, 0, (size_t)c->n * 9 * sizeof(float), c->stream));
     if (int rc = reset_status(c)) return rc;
@@ -824,7 +868,9 @@ int s2d_set_splats(s2d_ctx* c, const s2d_splat* splats)
 {
     if (!c || (!splats && c->n)) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
+    if (int rc = compact_flush(c)) return rc; // the moments of the held splats must not be lost with the compact copy
     S2D_HIP(c, hipMemcpyAsync(c->d_splats, splats, (size_t)c->n * sizeof(s2d_splat), hipMemcpyHostToDevice, c->stream));
+    if (int rc = compact_load(c)) return rc;
     if (int rc = clear_dormant(c)) return rc;
     if (int rc = reset_status(c)) return rc;
     S2D_HIP(c, hipStreamSynchronize(c->stream));
@@ -838,6 +884,7 @@ int s2d_get_splats(s2d_ctx* c, s2d_splat* splats)
 {
     if (!c || (!splats && c->n)) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
+    if (int rc = compact_flush(c)) return rc;
     S2D_HIP(c, hipMemcpyAsync(splats, c->d_splats, (size_t)c->n * sizeof(s2d_splat), hipMemcpyDeviceToHost, c->stream));
     S2D_HIP(c, hipStreamSynchronize(c->stream));
     return S2D_OK;
@@ -848,7 +895,9 @@ int s2d_set_adam(s2d_ctx* c, const s2d_splat_adam* adams, float beta1t, float be
     if (!c || (!adams && c->n) || iterations < 0) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
     if (int rc = flush_sqerr(c)) return rc; // (its ring slot is named by the iteration count about to change)
+    if (int rc = compact_flush(c)) return rc; // the parameters of the held splats must not be lost with the compact copy
     S2D_HIP(c, hipMemcpyAsync(c->d_adams, adams, (size_t)c->n * sizeof(s2d_splat_adam), hipMemcpyHostToDevice, c->stream));
+    if (int rc = compact_load(c)) return rc;
     if (int rc = clear_dormant(c)) return rc;
     S2D_HIP(c, hipStreamSynchronize(c->stream));
     c->beta1t = c->good_beta1t = beta1t;
@@ -862,6 +911,7 @@ int s2d_get_adam(s2d_ctx* c, s2d_splat_adam* adams, float* beta1t, float* beta2t
     if (!c) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
     if (adams) {
+        if (int rc = compact_flush(c)) return rc;
         S2D_HIP(c, hipMemcpyAsync(adams, c->d_adams, (size_t)c->n * sizeof(s2d_splat_adam), hipMemcpyDeviceToHost, c->stream));
         S2D_HIP(c, hipStreamSynchronize(c->stream));
     }
@@ -1019,6 +1069,7 @@ int s2d_halo_masks(s2d_ctx* c, int32_t world, const int32_t* row_bounds, float m
     for (int q = 0; q < world; q++)
         if (row_bounds[q] > row_bounds[q + 1]) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
+    if (int rc = compact_flush(c)) return rc;
     S2D_HIP(c, launch_halo_masks(c->d_splats, c->d_held, c->n, world, row_bounds, margin_rows, masks_device, c->stream));
     return S2D_OK;
 }
@@ -1027,6 +1078,8 @@ int s2d_halo_commit(s2d_ctx* c, const uint32_t* masks_device, int32_t rank, int3
 {
     if (!c || rank < 0 || rank > 31) return S2D_E_INVALID;
     if (int rc = use_device(c)) return rc;
+    if (int rc = compact_flush(c)) return rc; // the held set is about to change: the id-indexed arrays take over
+    c->compact_live = false;
     if (!masks_device) { // back to holding every splat (the caller has made this context's copy complete again)
         if (c->d_held) {
             S2D_HIP(c, hipStreamSynchronize(c->stream));
@@ -1049,6 +1102,7 @@ int s2d_halo_commit(s2d_ctx* c, const uint32_t* masks_device, int32_t rank, int3
     }
     S2D_HIP(c, launch_halo_commit(masks_device, c->n, rank, c->d_held, c->d_held_ids, c->d_held_count, c->d_held_work,
                                   c->d_scan_temp, c->stream));
+    if (int rc = compact_load(c)) return rc;
     if (added || first) {
         // splats arrived: project the held ones and rebuild the tile lists before the next forward
         c->lists_valid = false;
@@ -1076,6 +1130,8 @@ int s2d_rows_gather(s2d_ctx* c, int32_t what, const int32_t* ids_device, int32_t
     int w;
     if (int rc = rows_base(c, what, &base, &w)) return rc;
     if (int rc = use_device(c)) return rc;
+    if (what != S2D_ROWS_GRADS)
+        if (int rc = compact_flush(c)) return rc;
     S2D_HIP(c, launch_rows_gather(base, w, ids_device, count, c->n, out_device, c->stream));
     return S2D_OK;
 }
@@ -1087,9 +1143,14 @@ int s2d_rows_scatter(s2d_ctx* c, int32_t what, const int32_t* ids_device, int32_
     int w;
     if (int rc = rows_base(c, what, &base, &w)) return rc;
     if (int rc = use_device(c)) return rc;
+    if (what != S2D_ROWS_GRADS)
+        if (int rc = compact_flush(c)) return rc;
     S2D_HIP(c, launch_rows_scatter(base, w, ids_device, count, c->n, in_device, c->stream));
-    if (what == S2D_ROWS_SPLATS || what == S2D_ROWS_ADAM)
+    if (what == S2D_ROWS_SPLATS || what == S2D_ROWS_ADAM) {
+        if (c->compact_live)
+            if (int rc = compact_load(c)) return rc; // rows of held splats may be among them
         if (int rc = clear_dormant(c)) return rc;
+    }
     if (what == S2D_ROWS_SPLATS) { // parameters changed behind the projection
         c->proj_fresh = false;
         c->have_forward = false;

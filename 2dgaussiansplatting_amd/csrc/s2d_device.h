@@ -233,6 +233,9 @@ hipError_t launch_halo_masks(const float* splats, const uint8_t* held, int n, in
 // also builds ids[0 .. *count_dev): the held splats in ascending order (scan_work: n words, scan_temp: scan_temp_words(n))
 hipError_t launch_halo_commit(const uint32_t* masks, int n, int rank, uint8_t* held, uint32_t* ids, uint32_t* count_dev,
                               uint32_t* scan_work, uint32_t* scan_temp, hipStream_t stream);
+// compact[h][0..w) = base[ids[h]][0..w) for h < *count_dev (to_compact), or the other way round
+hipError_t launch_compact_copy(float* base, int w, const uint32_t* ids, const uint32_t* count_dev, int n, float* compact, bool to_compact,
+                               hipStream_t stream);
 hipError_t launch_rows_gather(const float* base, int w, const int* ids, int count, int n, float* out, hipStream_t stream);
 hipError_t launch_rows_scatter(float* base, int w, const int* ids, int count, int n, const float* in, hipStream_t stream);
 hipError_t launch_grads_combine(float* grads, const int* rows, int n_rows, const int* src, int world, const float* recv,
@@ -325,11 +328,13 @@ hipError_t launch_init_splats(float* splats, float* adams, int n, int W, int H, 
 // dormant (n bytes, or nullptr): dormant[i] = 1 while every Adam moment of splat i is zero -- maintained by the kernel,
 // cleared by whoever else writes splats or moments; a block whose splats are all dormant and received zero gradients skips
 // the step, which would leave them bit for bit as they are.
+// compact (only with held_ids): splats / adams are the COMPACT arrays of the held splats, record h = splat held_ids[h]:
+// whole lines instead of one gathered record per splat; gradients, projection and `dormant` stay indexed by splat id.
 hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t* held_ids, const uint32_t* held_count, int n,
                        Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
                        const TileRect* rects, int check_stamp, int* host_stamp, uint8_t* dormant, SqerrJob sq,
-                       hipStream_t stream);
+                       bool compact, hipStream_t stream);
 // image_ref: rows [row_begin, row_end) of the W x H target
 hipError_t launch_synthetic_target(void* image_ref, bool half_images, int W, int H, int row_begin, int row_end, hipStream_t stream);
 // RGBA32F <-> 4 x fp16 (round to nearest even) for images that cross the boundary as floats

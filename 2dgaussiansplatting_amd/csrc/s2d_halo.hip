@@ -105,6 +105,38 @@ __global__ __launch_bounds__(256) void grads_combine_kernel(float* __restrict__ 
     if (!first) grads[(size_t)i * 9 + k] = acc;
 }
 
+// Compact copies of the held splats' records (s2d_api.hip "compact held state"): out[h] = base[ids[h]] and back, for
+// h < *count (the launch covers n, the upper bound known to the host).
+__global__ __launch_bounds__(256) void compact_gather_kernel(const float* __restrict__ base, int w, const uint32_t* __restrict__ ids,
+                                                             const uint32_t* __restrict__ count, float* __restrict__ out)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)*count * w) return;
+    const int h = (int)(t / w), k = (int)(t - (long long)h * w);
+    out[t] = base[(size_t)ids[h] * w + k];
+}
+
+__global__ __launch_bounds__(256) void compact_scatter_kernel(float* __restrict__ base, int w, const uint32_t* __restrict__ ids,
+                                                              const uint32_t* __restrict__ count, const float* __restrict__ in)
+{
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)*count * w) return;
+    const int h = (int)(t / w), k = (int)(t - (long long)h * w);
+    base[(size_t)ids[h] * w + k] = in[t];
+}
+
+hipError_t launch_compact_copy(float* base, int w, const uint32_t* ids, const uint32_t* count_dev, int n, float* compact, bool to_compact,
+                               hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    const long long total = (long long)n * w;
+    if (to_compact)
+        hipLaunchKernelGGL(compact_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, base, w, ids, count_dev, compact);
+    else
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, base, w, ids, count_dev, compact);
+    return hipGetLastError();
+}
+
 hipError_t launch_halo_masks(const float* splats, const uint8_t* held, int n, int world, const int* row_bounds, float margin,
                              uint32_t* masks, hipStream_t stream)
 {

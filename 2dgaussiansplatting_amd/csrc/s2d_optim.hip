@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
                                                    float beta1t, float beta2t, float lr, int mode, int iteration,
                                                    DeviceStatus* __restrict__ status, ProjRec* __restrict__ proj,
                                                    const TileRect* __restrict__ rects, int check_stamp,
-                                                   int* __restrict__ host_stamp, uint8_t* __restrict__ dormant, SqerrJob sq)
+                                                   int* __restrict__ host_stamp, uint8_t* __restrict__ dormant, SqerrJob sq,
+                                                   int compact)
 {
     __shared__ __attribute__((aligned(16))) float buf[256 * 18];
     __shared__ uint32_t s_idbuf[256];
@@ -152,6 +153,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
         s_ids = s_idbuf;
         __syncthreads();
     }
+    // compact: record base + t of `splats` / `adams` IS splat ids[t]'s (the rank's held splats in a compact array of their
+    // own: whole lines, like the all-splats case); the gradient records stay where the raster kernels' atomics put them
+    const uint32_t* const s_ids_state = compact ? nullptr : s_ids;
     float v[9], mv[18], gr[9];
     // gradients in, zeros out
     lds_fill<9>(buf, grads, s_ids, base, cnt);
@@ -175,13 +179,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
     lds_drain<9>(grads, buf, s_ids, base, cnt);
     __syncthreads();
     // parameters in
-    lds_fill<9>(buf, splats, s_ids, base, cnt);
+    lds_fill<9>(buf, splats, s_ids_state, base, cnt);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 9; k++) v[k] = mine ? buf[t * 9 + k] : 0.0f;
     __syncthreads();
     // moments in
-    lds_fill<18>(buf, adams, s_ids, base, cnt);
+    lds_fill<18>(buf, adams, s_ids_state, base, cnt);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 18; k++) mv[k] = mine ? buf[t * 18 + k] : 0.0f;
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
         for (int k = 0; k < 18; k++) buf[t * 18 + k] = mv[k];
     }
     __syncthreads();
-    lds_drain<18>(adams, buf, s_ids, base, cnt);
+    lds_drain<18>(adams, buf, s_ids_state, base, cnt);
     __syncthreads();
     // parameters out
     if (mine) {
@@ -207,7 +211,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ splats, f
         for (int k = 0; k < 9; k++) buf[t * 9 + k] = v[k];
     }
     __syncthreads();
-    lds_drain<9>(splats, buf, s_ids, base, cnt);
+    lds_drain<9>(splats, buf, s_ids_state, base, cnt);
     if (proj && mine) project_updated(v, i, g, status, proj, rects, check_stamp, host_stamp);
 }
 
@@ -274,11 +278,12 @@ hipError_t launch_adam(float* splats, float* adams, float* grads, const uint32_t
                        int n, Geometry g, float beta1t, float beta2t,
                        float lr, int optimize_opacity, int iteration, DeviceStatus* status, ProjRec* proj,
                        const TileRect* rects, int check_stamp, int* host_stamp, uint8_t* dormant, SqerrJob sq,
-                       hipStream_t stream)
+                       bool compact, hipStream_t stream)
 {
     if (n <= 0) return hipSuccess; // (callers queue the standalone squared-error reduction themselves when n == 0)
     hipLaunchKernelGGL(adam_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, splats, adams, grads, held_ids, held_count, n, g,
-                       beta1t, beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, dormant, sq);
+                       beta1t, beta2t, lr, optimize_opacity, iteration, status, proj, rects, check_stamp, host_stamp, dormant, sq,
+                       (compact && held_ids) ? 1 : 0);
     return hipGetLastError();
 }
 
