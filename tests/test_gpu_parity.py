@@ -691,15 +691,21 @@ def test_images_wider_than_512_tile_columns(W, H, n, seed):
         t.backward()
         g = t.get_grads()
         assert t.stats()["pairs_binned"] > n
-    # Splats of up to 1024 px on a strip this wide sum ~1e5 terms per scalar, and the ORACLE's sequential fp32 sum is itself
-    # b_ref * sum|terms| away from the exact sum of those terms: bar (c), which is taken against the oracle's fp32 value with
-    # a floor of 0.02 * sum|terms|, is granted that much (50 * b_ref); bars (a) and (b) -- the GPU against the EXACT sum, and
-    # no further from it than the reference -- hold as everywhere.
+    # Splats of up to 1024 px on a strip this wide sum ~1e5..1e6 terms per scalar, and the ORACLE's sequential fp32 sum is itself
+    # b_ref * sum|terms| away from the exact sum of those terms (3e-5 at 8208 px, ten times its usual distance).  The bars are
+    # the usual three, scaled by that: (a) the GPU within max(1e-6, b_ref / 10) of the EXACT sum (measured 7e-7..9e-7 against a
+    # b_ref of 3.2e-5, run-to-run: float atomics); (b) no further from it than the reference's own order; (c) against the
+    # oracle's fp32 value -- floor 0.02 * sum|terms| -- within max(1e-4, 10 * b_ref) (measured 1.1e-4).
     w32, dsum, dabs = o.backward_stats()
+    gg = g.view(np.float32).reshape(-1, 9).astype(np.float64)
+    ww = w32.view(np.float32).reshape(-1, 9).astype(np.float64)
     nz = dabs > 0
-    b_ref = float((np.abs(w32.view(np.float32).reshape(-1, 9).astype(np.float64) - dsum)[nz] / dabs[nz]).max())
-    bars = O.grad_bars(g.view(np.float32), w32.view(np.float32), dsum, dabs, max(REL, 50.0 * b_ref))
-    assert bars["a_gpu_vs_exact"] <= 1e-6 and bars["c_gpu_vs_oracle"] <= 3e-4, bars
+    assert np.all(gg[~nz] == 0)
+    b_ref = float((np.abs(ww - dsum)[nz] / dabs[nz]).max())
+    a = float((np.abs(gg - dsum)[nz] / dabs[nz]).max())
+    c = float((np.abs(gg - ww)[nz] / np.maximum(np.abs(ww[nz]), 0.02 * dabs[nz])).max())
+    assert a <= max(1e-6, 0.1 * b_ref) and a <= b_ref, (a, b_ref)
+    assert c <= max(REL, 10.0 * b_ref), (c, b_ref)
     o = O.OracleTrainer(tgt, n)
     o.splats[:] = s
     with S2D.Trainer(W, H, n) as t:
