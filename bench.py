@@ -103,11 +103,11 @@ def stage(rank, name):
 
 def watchdog_budget(args):
     """Wall-clock budget of one attempt of the child job, from the amount of work asked for: import + rendezvous + RCCL
-    set-up (up to ~3 minutes on a fresh box) + the iterations (warm-up, timed block, side block, the run up to iteration
-    200 for the PSNR) at a generous 10 ms each.  184 s for the default --steps 100."""
+    set-up (N first imports of torch on a fresh box take minutes) + the iterations (warm-up, timed block, side block, the run
+    up to iteration 200 for the PSNR) at a generous 10 ms each.  239 s for the default --steps 100."""
     if args.watchdog_seconds > 0:
         return float(args.watchdog_seconds)
-    return 180.0 + 0.01 * (args.warmup + 2 * args.steps + 200)
+    return 235.0 + 0.01 * (args.warmup + 2 * args.steps + 200)
 
 
 def run_ranks_once(n, argv, budget_s):
@@ -193,7 +193,7 @@ def spawn_ranks(n, argv, args):
         return 0
     stalled = res["rc"] is None
     got_going = STAGES.index(res["stage"]) >= STAGES.index("selftest")
-    left = 540.0 - (time.perf_counter() - t_all)
+    left = 570.0 - (time.perf_counter() - t_all)
     if stalled and got_going and args.exchange is None and not args.launch_selftest and left >= 60.0:
         print("bench.py: the ranks stopped answering at stage '%s' with the default exchange (halo); one fresh attempt with "
               "--exchange dense" % res["stage"], file=sys.stderr)
@@ -240,7 +240,7 @@ def main():
                     "to rehearse the multi-process path with several ranks sharing one GPU)")
     ap.add_argument("--watchdog-seconds", type=float, default=0.0,
                     help="N > 1 started from the plain command: wall-clock budget of the child job before the parent stops it and "
-                         "prints an error record (0 = derived from --steps: 180 s + 10 ms per iteration)")
+                         "prints an error record (0 = derived from --steps: 235 s + 10 ms per iteration)")
     ap.add_argument("--launch-selftest", action="store_true",
                     help="only check the multi-process launch path: the ranks rendezvous, all-reduce their rank numbers "
                          "and rank 0 prints one JSON line; needs no GPU (tests/test_distributed_cpu.py)")
