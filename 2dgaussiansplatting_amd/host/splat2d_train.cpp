@@ -224,6 +224,14 @@ int main(int argc, char** argv)
     if (o.gpus < 1) return usage();
     Session S;
     CK(S.create(o, W, H));
+    if (S.is_multi) { // which GPU runs which rows (stderr: stdout is the reference's trace)
+        for (int r = 0; r < s2d_multi_device_count(S.multi); r++) {
+            int32_t dev = 0, r0 = 0, r1 = 0;
+            char pci[64] = "", name[128] = "";
+            if (s2d_multi_device_info(S.multi, r, &dev, &r0, &r1, pci, (int32_t)sizeof(pci), name, (int32_t)sizeof(name)) == S2D_OK)
+                std::fprintf(stderr, "rank %d: device %d (%s, %s), rows %d..%d\n", r, dev, pci, name, r0, r1);
+        }
+    }
     CK(S.set_target(imageRef)); // (empty: the synthetic target is generated on the device)
     CK(S.init());               // init(); main.cpp:307
 

@@ -1303,6 +1303,8 @@ def test_cpp_host_n_ranks_sharing_the_gpu(world, exchange):
     np.testing.assert_allclose([float(l.split("mse")[1]) for l in got], [float(l.split("mse")[1]) for l in want], rtol=2e-5)
     assert "%d ranks" % world in p.stderr
     assert ("slab ownership" if exchange == "halo" else "replicated state") in p.stderr
+    for r in range(world):     # which GPU runs which rows (s2d_multi_device_info)
+        assert any(ln.startswith("rank %d: device 0 (" % r) and "rows " in ln for ln in p.stderr.splitlines()), p.stderr
 
 
 @pytest.mark.parametrize("world,replicated", [(2, False), (3, False), (2, True), (3, True)])
