@@ -407,15 +407,16 @@ __device__ __forceinline__ float wave_sum8_lds(float* sw, int lane, float a0, fl
 
 // num / den as IEEE division would round it, from the hardware reciprocal r = v_rcp_f32(den) (1 ulp) shared by several
 // numerators: quotient estimate, then ONE correction q += (num - den*q) * r whose residual is exact (fma).  The estimate
-// is off by up to ~1.5 ulp; the corrected value is the correctly rounded quotient unless the true quotient lies within
-// ~3e-7 ulp of a rounding boundary -- 0 or 1 of 20 M random (S, 1 - alpha) pairs differ from IEEE division, whether r is
-// the rounded reciprocal or one ulp to either side of it, and a second or third correction changes none of them
-// (tools/check_recip_division.py).  Rounds 1-3 applied two corrections: six more instructions per executed (wave,
-// entry), same parity statistics, -2.9 % (profiles/r03/ab_one_division_correction.txt).  No per-division scaling for
-// denormal / huge operands: they cannot occur here (den in [1e-15, 1], |num| <~ 1).
-// The quotient must be the one the reference computes:
+// is off by up to ~1.5 ulp.  Measured on 3 x 10^8 operand pairs of this blend's range, den = 1e-15 and quotients next to
+// rounding midpoints included (tools/check_recip_division.py, profiles/r04/r04_recip_division_check.txt): with a correctly
+// rounded r the corrected value is the IEEE quotient in every trial; with r one ulp off, 7-9 quotients per 10^8 differ from
+// IEEE division (1-2 per 10^8 after a second correction) -- at ~10^9 quotients per iteration of 4096^2 / 1 M that is at most a
+// few dozen one ulp off per iteration.  Rounds 1-3 applied two corrections: six more instructions per executed (wave, entry),
+// same parity statistics, -2.9 % (profiles/r03/ab_one_division_correction.txt).  No per-division scaling for denormal / huge
+// operands: they cannot occur here (den in {1e-15} u [2^-24, 1], |num| <~ 1).
+// The quotient should be the one the reference computes:
 // c*T - S/(1-alpha) cancels down to a T_final-sized remainder, which magnifies a last-place difference in the
-// quotient by T/T_final (10^3..10^5 in flat image regions).
+// quotient by T/T_final (10^3..10^5 in flat image regions); the gradient bars are what is asserted.
 __device__ __forceinline__ float div_by_recip(float num, float den, float r)
 {
     const float q = num * r;
