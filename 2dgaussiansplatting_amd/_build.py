@@ -88,6 +88,22 @@ def build_host_program(force=False, verbose=False):
     return TRAIN_BIN
 
 
+def build_experiment(name, defines=(), csrc=None, verbose=False):
+    """An A/B or diagnostic build of the same ABI for tools/gpu_ab*.py (`S2D_LIBRARY=<path>` selects it): written to
+    <repo>/build/, NEVER into the package's lib/ -- lib/ holds the product (libsplat2d_hip.so, splat2d_train) and nothing else.
+    csrc: a directory with a patched copy of the sources (default: the tree's)."""
+    out_dir = os.path.join(ROOT, "build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libsplat2d_hip_%s.so" % name)
+    src_dir = csrc or CSRC
+    cmd = [hipcc()] + HIPCC_FLAGS + ["-I", os.path.join(ROOT, "include")] + ["-D" + d for d in defines] + ["-o", out] + \
+          [os.path.join(src_dir, s) for s in HIP_SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_all(force=False, verbose=False):
     lib = build_hip_library(force=force, verbose=verbose)
     build_host_program(force=force, verbose=verbose)

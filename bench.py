@@ -95,10 +95,44 @@ def kernel_source_digest():
 STAGES = ["spawn", "start", "init", "selftest", "warmup", "timed", "psnr", "side-block", "report", "done"]
 
 
+_STAGE = {"name": "spawn"}
+
+
 def stage(rank, name):
     """Stage marker of a rank, on stderr: the parent's watchdog keeps the latest one so that a run that stops says where."""
+    _STAGE["name"] = name
     sys.stderr.write("[bench stage] rank %d: %s\n" % (rank, name))   # ONE write: the ranks share the pipe
     sys.stderr.flush()
+
+
+def start_rank_watchdog(args, rank, world):
+    """A rank started by somebody else's launcher (the driver runs `python -m torch.distributed.run ... bench.py --gpus N`
+    itself: no parent of ours watches it) must not end as a silent kill either.  A timer thread with the same budget: when it
+    fires, rank 0 prints the ONE JSON line -- an error record with the stage it had reached -- and every rank leaves with
+    exit code 4, which makes the launcher stop the job.  (A rank stuck inside a collective still runs this thread: the
+    collectives release the interpreter lock.)  Under our own parent the timer is set a little later than the parent's, which
+    reports more (every rank's stage, the stderr tail).  Returns the timer: cancel it once the result is out."""
+    import threading
+    budget = watchdog_budget(args) + (15.0 if os.environ.get("S2D_BENCH_PARENT") == "1" else 0.0)
+    if rank != 0:
+        budget += 5.0   # rank 0 writes the record before another rank's exit makes the launcher stop everybody
+
+    def fire():
+        why = ("rank %d of %d produced no result within %.0f s; it was at stage '%s' (a collective or a peer that never answered, or "
+               "a device that stopped)" % (rank, world, budget, _STAGE["name"]))
+        sys.stderr.write("bench.py watchdog: %s\n" % why)
+        sys.stderr.flush()
+        if rank == 0:
+            sys.stdout.write(json.dumps({"metric": "train iters/sec (fwd+bwd+Adam) + PSNR vs ref; 4K img, 1M splats", "value": None,
+                                         "unit": "iterations/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                                         "error": why, "stage": _STAGE["name"], "watchdog_budget_s": budget}) + "\n")
+            sys.stdout.flush()
+        os._exit(4)
+
+    t = threading.Timer(budget, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def watchdog_budget(args):
@@ -126,6 +160,7 @@ def run_ranks_once(n, argv, budget_s):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "1")
+    env["S2D_BENCH_PARENT"] = "1"   # the ranks' own watchdogs then fire after this parent's
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
     t0 = time.perf_counter()
@@ -255,6 +290,7 @@ def main():
         import datetime
         world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
         stage(rank, "start")
+        dog = start_rank_watchdog(args, rank, world) if world > 1 else None
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist_mod.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=120))
@@ -269,6 +305,8 @@ def main():
             dist_mod.barrier()
         if os.environ.get("S2D_BENCH_SELFTEST_FAIL_RANK") == str(rank):
             sys.exit(7)  # lets the test see that a failing rank fails the whole command
+        if dog is not None:
+            dog.cancel()
         if rank == 0:
             print(json.dumps({"selftest": "launch", "world": world, "sum": int(v.item()), "gpus_arg": args.gpus}))
         if world > 1:
@@ -285,6 +323,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     stage(rank, "start")
+    dog = start_rank_watchdog(args, rank, world) if world > 1 else None
     if world != args.gpus:
         args.gpus = world  # the launcher's world size wins
     if not torch.cuda.is_available():
@@ -582,7 +621,11 @@ def main():
             out["cpu_baseline"] = cpu_baseline(W, H, n, threads)
         else:
             out["cpu_baseline"] = None
+        if dog is not None:
+            dog.cancel()
         print(json.dumps(out))
+    elif dog is not None:
+        dog.cancel()
     t.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -319,3 +319,28 @@ def test_bench_watchdog_reports_a_rank_that_stops_answering():
     # nothing of the job is left behind
     left = subprocess.run(["ps", "-eo", "pid,args"], capture_output=True, text=True).stdout
     assert not any("--launch-selftest" in ln and "--watchdog-seconds 25" in ln for ln in left.splitlines()), left
+
+
+def test_bench_rank_watchdog_when_somebody_elses_launcher_starts_the_ranks():
+    """The driver starts the ranks itself (`python -m torch.distributed.run ... bench.py --gpus N`): no parent of ours watches
+    them.  Each rank then carries its own watchdog timer: with one rank asleep for ever the job still ends inside the budget,
+    rank 0 prints the ONE JSON line -- an error record naming the stage it was at -- and the launcher returns non-zero."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "S2D_BENCH_PARENT")}
+    env["S2D_BENCH_SELFTEST_HANG_RANK"] = "1"
+    t0 = time.perf_counter()
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--launch-selftest",
+                        "--watchdog-seconds", "20"], env=env, capture_output=True, text=True, timeout=300)
+    dt = time.perf_counter() - t0
+    assert p.returncode != 0
+    assert dt < 20 + 40, dt
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["value"] is None and "no result within 20 s" in out["error"] and out["stage"] in ("init", "selftest"), out
+    assert "bench.py watchdog: rank" in p.stderr
