@@ -713,7 +713,10 @@ def test_images_wider_than_512_tile_columns(W, H, n, seed):
         t.set_splats(s)
         got = t.step(3)
     want = [o.step()[1] for _ in range(3)]
-    np.testing.assert_allclose(got, want, rtol=2e-5)
+    # (one-pixel-thin and 1024-px splats side by side: a last-place difference in a gradient sum flips a pixel's inclusion
+    # a step later, so the bar on the third value is 1e-4; measured 1e-6 .. 2.5e-5 from run to run)
+    assert abs(got[0] - want[0]) <= 1e-9 * want[0]
+    np.testing.assert_allclose(got, want, rtol=1e-4)
 
 
 def test_low_opacity_deep_stacks():
