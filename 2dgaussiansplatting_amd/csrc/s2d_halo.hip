@@ -7,6 +7,8 @@
 // projection uses).  Holders keep bit-identical copies: each adds the holders' partial gradients in ascending rank
 // order (grads_combine_kernel) and applies the same Adam step.  The host (distributed.HaloStep) moves the rows
 // between ranks with torch.distributed; these kernels only classify, gather, scatter and combine rows.
+#include <algorithm>
+
 #include "s2d_device.h"
 
 namespace s2d {
@@ -110,19 +112,21 @@ __global__ __launch_bounds__(256) void grads_combine_kernel(float* __restrict__ 
 __global__ __launch_bounds__(256) void compact_gather_kernel(const float* __restrict__ base, int w, const uint32_t* __restrict__ ids,
                                                              const uint32_t* __restrict__ count, float* __restrict__ out)
 {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)*count * w) return;
-    const int h = (int)(t / w), k = (int)(t - (long long)h * w);
-    out[t] = base[(size_t)ids[h] * w + k];
+    const long long total = (long long)*count * w; // (the host knows only the upper bound n: a fixed grid strides over what there is)
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int h = (int)(t / w), k = (int)(t - (long long)h * w);
+        out[t] = base[(size_t)ids[h] * w + k];
+    }
 }
 
 __global__ __launch_bounds__(256) void compact_scatter_kernel(float* __restrict__ base, int w, const uint32_t* __restrict__ ids,
                                                               const uint32_t* __restrict__ count, const float* __restrict__ in)
 {
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (long long)*count * w) return;
-    const int h = (int)(t / w), k = (int)(t - (long long)h * w);
-    base[(size_t)ids[h] * w + k] = in[t];
+    const long long total = (long long)*count * w;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int h = (int)(t / w), k = (int)(t - (long long)h * w);
+        base[(size_t)ids[h] * w + k] = in[t];
+    }
 }
 
 hipError_t launch_compact_copy(float* base, int w, const uint32_t* ids, const uint32_t* count_dev, int n, float* compact, bool to_compact,
@@ -130,10 +134,11 @@ hipError_t launch_compact_copy(float* base, int w, const uint32_t* ids, const ui
 {
     if (n <= 0) return hipSuccess;
     const long long total = (long long)n * w;
+    const unsigned blocks = (unsigned)std::min<long long>((total + 255) / 256, 4096); // 16 per CU: enough to stream, few to retire empty
     if (to_compact)
-        hipLaunchKernelGGL(compact_gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, base, w, ids, count_dev, compact);
+        hipLaunchKernelGGL(compact_gather_kernel, dim3(blocks), dim3(256), 0, stream, base, w, ids, count_dev, compact);
     else
-        hipLaunchKernelGGL(compact_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, base, w, ids, count_dev, compact);
+        hipLaunchKernelGGL(compact_scatter_kernel, dim3(blocks), dim3(256), 0, stream, base, w, ids, count_dev, compact);
     return hipGetLastError();
 }
 

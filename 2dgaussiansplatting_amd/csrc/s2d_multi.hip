@@ -948,8 +948,7 @@ void run_command(s2d_multi* m, int cmd)
                     snprintf(one, sizeof(one), "%srank %d (device %d) at '%s', iteration %d", who.empty() ? "" : "; ", r, m->devices[(size_t)r],
                              phase_name(P.phase.load()), P.iteration.load());
                     who += one;
-                    m->rank_rc[(size_t)r] = S2D_E_STATE;
-                    m->rank_msg[(size_t)r] = "did not come back";
+                    m->rank_rc[(size_t)r] = S2D_E_STATE; // (under m->m, like the workers' own writes; their message strings are theirs)
                 }
             m->stuck = true;
             m->dead = true;
