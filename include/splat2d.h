@@ -134,7 +134,7 @@ typedef struct s2d_config {
 typedef struct s2d_stats {
     uint32_t struct_size;      /* IN: sizeof(s2d_stats) as the caller was compiled; s2d_get_stats writes no more than that */
     uint32_t reserved;
-    uint64_t pairs_binned;     /* (tile, splat) pairs in the current tile lists */
+    uint64_t pairs_binned;     /* (tile, splat) pairs in the current tile lists (index-range rendering: of the range built last) */
     uint64_t pairs_capacity;
     uint64_t rebins;           /* times the tile lists were rebuilt */
     uint64_t fwd_visited, fwd_active; /* S2D_CFG_COUNT_PAIRS: pairs inside the reference's x/y ranges, and those with T >= 1/256 */
@@ -174,7 +174,12 @@ int s2d_get_splats(s2d_ctx* ctx, s2d_splat* splats);
 int s2d_set_adam(s2d_ctx* ctx, const s2d_splat_adam* adams, float beta1t, float beta2t, int32_t iterations);
 int s2d_get_adam(s2d_ctx* ctx, s2d_splat_adam* adams, float* beta1t, float* beta2t, int32_t* iterations);
 
-/* Forward rasteriser, main.cpp:414-546 (rows of this context's slab). */
+/* Forward rasteriser, main.cpp:414-546 (rows of this context's slab).
+ * No scene the reference's loops can run is refused for its size: the (tile, splat) pairs of the tile lists are addressed
+ * with 32 bits, and a scene with more of them than S2D_CHUNK_PAIRS (environment, read at s2d_create; default 2^30) is
+ * rendered by consecutive INDEX RANGES of the splats -- the lists of one range at a time, front to back like main.cpp:419
+ * and :552, the per-pixel colour and throughput carried from range to range -- with the same bits as one set of lists
+ * (forward, backward and s2d_step alike; only S2D_CFG_COUNT_PAIRS contexts answer S2D_E_NOMEM there). */
 int s2d_forward(s2d_ctx* ctx);
 /* image0 as uploaded at main.cpp:794: width*height RGBA32F, .w = 1.  Rows outside the slab are returned as 0. */
 int s2d_get_image(s2d_ctx* ctx, float* rgba32f);
