@@ -463,9 +463,22 @@ def main():
     # does by itself while "Optimize opacity" is off, because Adam reads dSplats.opacity only with it on, main.cpp:735) --
     # same trajectory, the NEED_OP = false instantiation of the raster kernel.
     lean = None
+    late = None
     want_lean = args.lean_block if args.lean_block is not None else world == 1
     if want_lean and args.steps > 0:
+        # ... and, first, the SAME nine-gradient steps timed again here, after iteration 200: an iteration gets cheaper as
+        # training goes on (front splats sharpen, pixels saturate earlier), so `value` -- timed over the first iterations after
+        # init(), the dearest of a run -- reads lower than any later window of the same run.  (Round 3 timed its nine-gradient
+        # block at this point of the run.)
         stage(rank, "side-block")
+        for _ in range(min(args.warmup, 5)):
+            one_step()
+        fb = timed_block(args.steps)
+        late = {"iterations_per_s": args.steps / fb["seconds"], "ms_per_step": 1e3 * fb["seconds"] / args.steps,
+                "iterations_per_s_median": 1e3 / float(np.median(fb["step_ms"])), "iterations_per_s_steady_state": 1e3 / fb["steady_ms"],
+                "steps_with_list_rebuild": int(fb["rebuilds"].sum()), "kernel_ms": fb["kernel_ms"], "steps": args.steps,
+                "first_iteration": int(t.stats()["iterations"]) - args.steps,
+                "backward": "all nine gradients, like `value`; timed after iteration 200 instead of right after init()"}
         t.lean_backward = True
         for _ in range(min(args.warmup, 5)):
             one_step()
@@ -537,6 +550,10 @@ def main():
             # off, main.cpp:317,735; what s2d_step does by itself), timed the same way
             "iterations_per_s_lean": lean["iterations_per_s"] if lean else None,
             "lean_backward": lean,
+            # the nine-gradient iteration again, later in the same run (NOT `value`): iterations get cheaper as training goes on
+            "iterations_per_s_after_200_iterations": late["iterations_per_s"] if late else None,
+            "nine_gradients_after_200_iterations": late,
+            "value_window": "iterations %d..%d after init() (the dearest of a run)" % (first, first + args.steps - 1),
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
