@@ -133,12 +133,13 @@ class OracleTrainer:
                                   C.byref(counters) if counters is not None else None)
         return self.dsplats
 
-    def backward_stats(self):
-        """Backward pass + (dsum, dabs): the fp32 contributions summed in double, and the sum of their magnitudes."""
+    def backward_stats(self, y0=0, y1=None):
+        """Backward pass (rows y0..y1) + (dsum, dabs): the fp32 contributions summed in double, and the sum of their magnitudes."""
+        y1 = self.H if y1 is None else y1
         self.dsplats[:] = 0
         dsum = np.zeros((self.n, 9), dtype=np.float64)
         dabs = np.zeros((self.n, 9), dtype=np.float64)
-        self.L.s2do_backward_rows_stats(_p(self.splats), self.n, self.W, self.H, 0, self.H, _p(self.image0),
+        self.L.s2do_backward_rows_stats(_p(self.splats), self.n, self.W, self.H, y0, y1, _p(self.image0),
                                         _p(self.ref), _p(self.image1), _p(self.dsplats), _p(dsum), _p(dabs))
         return self.dsplats, dsum, dabs
 

@@ -196,6 +196,57 @@ def test_forward_bitwise_adversarial(W, H, n, seed):
     assert got.tobytes() == want.tobytes()
 
 
+@pytest.mark.parametrize("seed", range(64))
+def test_forward_and_gradients_random_sweep(seed):
+    """Differential sweep: random image sizes (down to one pixel, not tile multiples), splat counts (down to none),
+    adversarial splats, and a random variant of the path -- one set of lists (both builders), index ranges with a small pair
+    budget, a row slab, fp16 images, deterministic sums.  Forward bit-exact against the oracle (on the slab's rows), gradients
+    within the three bars."""
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.integers(1, 300)), int(rng.integers(1, 220))
+    n = int(rng.choice([0, 1, 3, 40, 300, 700]))
+    variant = ["plain", "generic", "chunks", "slab", "fp16", "det", "chunks+det", "slab+chunks"][seed % 8]
+    kw = {}
+    if "generic" in variant:
+        kw["generic_binning"] = True
+    if "chunks" in variant:
+        kw["chunk_pairs"] = int(rng.choice([1, 50, 400]))
+    if "det" in variant:
+        kw["deterministic"] = True
+    if "fp16" in variant:
+        kw["fp16_images"] = True
+    r0, r1 = 0, H
+    if "slab" in variant and H > 16:
+        r0 = int(rng.integers(0, (H - 1) // 16 + 1)) * 16
+        r0 = min(r0, ((H - 1) // 16) * 16)
+        r1 = min(H, r0 + 16 * int(rng.integers(1, 5)))
+        kw.update(row_begin=r0, row_end=r1)
+    tgt = O.synthetic_target(W, H)
+    if "fp16" in variant:
+        tgt = _fp16(tgt)
+    s = random_splats(n, W, H, 2000 + seed)
+    o = O.OracleTrainer(tgt, n)
+    o.splats[:] = s
+    want = o.forward(r0, r1).copy()
+    with S2D.Trainer(W, H, n, **kw) as t:
+        t.set_target(tgt)
+        t.set_splats(s)
+        t.forward()
+        got = t.get_image()
+        if "fp16" in variant:
+            want = _fp16(want)
+            o.image0[:] = want          # the backward pass reads the framebuffer as stored
+        assert got[r0:r1].tobytes() == want[r0:r1].tobytes(), (W, H, n, variant, kw)
+        t.backward()
+        g = t.get_grads()
+    if n:
+        w32, dsum, dabs = o.backward_stats(r0, r1)
+        if (dabs > 0).any():
+            O.grad_bars(g.view(np.float32), w32.view(np.float32), dsum, dabs, REL)
+        else:                       # no splat reaches a live pixel of these rows
+            assert not g.view(np.float32).any()
+
+
 def test_forward_no_splats():
     with S2D.Trainer(40, 30, 0) as t:
         t.set_target(O.synthetic_target(40, 30))
