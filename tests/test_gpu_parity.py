@@ -247,6 +247,34 @@ def test_forward_and_gradients_random_sweep(seed):
             assert not g.view(np.float32).any()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_training_steps_random_sweep(seed):
+    """Whole iterations (s2d_step: fused forward + backward, Adam, MSE) from init() on random image sizes and splat counts,
+    with "Optimize opacity" on or off and a random variant of the path: the MSE trace follows the oracle's -- iteration 0 to
+    1e-9 (same framebuffer, double sum in another order), the next ones to 2e-5 -- and the parameters after 5 steps agree to
+    the update bar of the single-step test, summed over the steps."""
+    rng = np.random.default_rng(5000 + seed)
+    W, H = int(rng.integers(40, 400)), int(rng.integers(40, 300))
+    n = int(rng.choice([5, 200, 1500]))
+    opacity = bool(seed & 1)
+    variant = ["plain", "generic", "chunks", "det"][(seed >> 1) % 4]
+    kw = {"generic_binning": True} if variant == "generic" else {"chunk_pairs": int(rng.choice([30, 2000]))} if variant == "chunks" else \
+         {"deterministic": True} if variant == "det" else {}
+    tgt = O.synthetic_target(W, H)
+    o = O.OracleTrainer(tgt, n, optimize_opacity=opacity)
+    want = np.array([o.step()[1] for _ in range(5)])
+    with S2D.Trainer(W, H, n, **kw) as t:
+        t.optimize_opacity = opacity
+        t.set_target(tgt)
+        t.init()
+        got = t.step(5)
+        sp = t.get_splats().view(np.float32).reshape(-1, 9).astype(np.float64)
+    assert abs(got[0] - want[0]) <= 1e-9 * want[0], (W, H, n, variant, opacity)
+    np.testing.assert_allclose(got, want, rtol=2e-5)
+    ws = o.splats.view(np.float32).reshape(-1, 9).astype(np.float64)
+    assert np.abs(sp - ws).max() <= 5 * 1e-3 * 0.05 + 1e-5 * np.abs(ws).max(), np.abs(sp - ws).max()
+
+
 def test_forward_no_splats():
     with S2D.Trainer(40, 30, 0) as t:
         t.set_target(O.synthetic_target(40, 30))
