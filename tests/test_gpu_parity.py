@@ -1457,6 +1457,46 @@ def test_multi_device_handle_ownership_equals_replicated_state_bit_for_bit(world
         assert out[False][k] == out[True][k], name
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_multi_device_handle_random_sweep(seed):
+    """Random rank counts (2..6 on this one GPU), image sizes and splat counts, 140+ iterations in uneven calls across two
+    hold-set refreshes, with the Adam state read back and written again in the middle (which empties and refills the ranks'
+    compact copies of their held splats): slab ownership and replicated state agree bit for bit, and both follow the single
+    context's trace."""
+    rng = np.random.default_rng(7000 + seed)
+    world = int(rng.integers(2, 7))
+    W = int(rng.integers(64, 500))
+    H = int(rng.integers(16 * world, 16 * world + 500))
+    n = int(rng.choice([300, 2000, 8000]))
+    calls = [int(c) for c in rng.integers(1, 80, size=4)] + [70]
+    tgt = O.synthetic_target(W, H)
+    out = {}
+    for replicated in (False, True):
+        with S2D.MultiTrainer(W, H, n, [0] * world, share_gpu=True, deterministic=True, replicated=replicated) as m:
+            m.set_target(tgt)
+            m.init()
+            tr = []
+            for k, c in enumerate(calls):
+                tr.append(m.step(c))
+                if k == 1:
+                    ad, b1, b2, it = m.get_adam()
+                    m.set_adam(ad, b1, b2, it)
+                if k == 2:
+                    m.set_splats(m.get_splats())
+            tr = np.concatenate(tr)
+            out[replicated] = (tr.tobytes(), m.get_splats().tobytes(), m.get_adam()[0].tobytes(), tr)
+    for k, name in enumerate(["trace", "splats", "adam"]):
+        assert out[False][k] == out[True][k], (name, world, W, H, n, calls)
+    with S2D.Trainer(W, H, n) as t:
+        t.set_target(tgt)
+        t.init()
+        want = t.step(sum(calls))
+    # (the single context sums gradients with float atomics in another order: the runs drift apart slowly)
+    np.testing.assert_allclose(out[False][3][:60], want[:60], rtol=5e-4)
+    np.testing.assert_allclose(out[False][3], want, rtol=2e-2)
+    assert abs(out[False][3][0] - want[0]) <= 1e-9 * want[0]
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_multi_device_handle_forward_after_new_splats_uses_fresh_hold_sets(world):
     """step -> set_splats(other values) -> forward on a slab-ownership handle: the hold sets of the stepped run say
