@@ -242,6 +242,7 @@ struct s2d_multi {
     std::atomic<bool> collective_lost{false}; // some communicator really was aborted
     std::atomic<bool> timed_out{false};       // some wait ran out: the ranks no longer agree on where the run stands
     bool dead = false;              // a collective was aborted or a rank stopped answering: the handle must be re-created
+    bool failed_step = false;       // the last step failed: the ranks stand at different iterations until the state is set afresh
     bool stuck = false;             // ... and some worker never came back: its thread and context are abandoned, not freed
     // A rank that stops answering (a device wait that never ends, a thread that died) must not hang the caller: every
     // wait of one rank for another, and for its own stream, gives up after this long without progress (milliseconds;
@@ -803,8 +804,12 @@ int rank_step(s2d_multi* m, int rank)
                 // this rank's own slot: nobody frees what it holds while comms_aborted is clear, and once it is set no
                 // collective is started any more
                 const ncclComm_t comm = m->comms_aborted.load() ? nullptr : m->comms[(size_t)rank].load();
-                if (!comm) rc = stopped(m, rank) ? kStopped : rank_fail(m, rank, S2D_E_STATE, "no communicator (aborted)");
-                else if (m->rccl.AllReduce(grads, grads, count, ncclFloat, ncclSum, comm, stream) != ncclSuccess)
+                if (m->comms_aborted.load()) { // a stop was published (the barrier breaks a moment later): not this rank's failure
+                    abort_own_collective(m, rank);
+                    rc = kStopped;
+                } else if (!comm) {
+                    rc = rank_fail(m, rank, S2D_E_STATE, "no communicator");
+                } else if (m->rccl.AllReduce(grads, grads, count, ncclFloat, ncclSum, comm, stream) != ncclSuccess)
                     rc = rank_fail(m, rank, S2D_E_HIP, "ncclAllReduce failed");
             }
         }
@@ -1241,6 +1246,7 @@ int s2d_multi_init_splats(s2d_multi* m)
     DeviceGuard guard;
     S2D_EACH(m, "s2d_init_splats", s2d_init_splats(c)); // every replica: the same deterministic init(), main.cpp:280-305
     m->iterations = 0;
+    m->failed_step = false;
     m->hold_valid = false; // every replica is complete again: new hold sets at the next step
     return S2D_OK;
 }
@@ -1291,6 +1297,7 @@ int s2d_multi_set_adam(s2d_multi* m, const s2d_splat_adam* adams, float beta1t, 
     DeviceGuard guard;
     S2D_EACH(m, "s2d_set_adam", s2d_set_adam(c, adams, beta1t, beta2t, iterations)); // complete on every rank; hold sets unaffected
     m->iterations = iterations;
+    m->failed_step = false; // every rank's counters are alike again (the caller sets the splats as well: include/splat2d.h)
     return S2D_OK;
 }
 
@@ -1298,6 +1305,9 @@ int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out)
 {
     if (!m || iters < 0 || iters > (1 << 16)) return S2D_E_INVALID;
     if (m->dead) return refuse_dead(m);
+    if (m->failed_step)
+        return mfail(m, S2D_E_STATE, "the last s2d_multi_step failed and left the ranks at different iterations: s2d_multi_init_splats, or "
+                                     "s2d_multi_set_splats + s2d_multi_set_adam, first");
     DeviceGuard guard;
     if (int rc = ensure_hold(m)) return rc;
     m->step_iters = iters;
@@ -1316,6 +1326,7 @@ int s2d_multi_step(s2d_multi* m, int32_t iters, uint32_t flags, double* mse_out)
         }
         if (earliest != INT32_MAX) m->iterations = earliest;
         if (m->collective_lost.load() || m->timed_out.load()) m->dead = true;
+        m->failed_step = true;
         return rc;
     }
     m->iterations += iters;

@@ -264,8 +264,10 @@ int s2d_synchronize(s2d_ctx* ctx);
  *    summed in place by an RCCL all-reduce (on each context's stream, between s2d_forward_backward and s2d_adam_step),
  *    the identical Adam step everywhere.  RCCL is loaded (dlopen) when such a handle is created.
  * With deterministic gradients (S2D_CFG_DETERMINISTIC) and sums formed in rank order the two give the same bits.
- * After a failed s2d_multi_step (S2D_E_NONFINITE: the reference abort()s there) the state is for inspection only;
- * s2d_multi_init_splats, or s2d_multi_set_splats + s2d_multi_set_adam, make the handle usable again. */
+ * After a failed s2d_multi_step (S2D_E_NONFINITE: the reference abort()s there; or one rank's own failure, reported with that
+ * rank's number and message) the ranks stand at different iterations and the state is for inspection only: further steps are
+ * refused (S2D_E_STATE) until s2d_multi_init_splats, or s2d_multi_set_splats + s2d_multi_set_adam, set it afresh -- unless a
+ * collective had to be aborted or a rank stopped answering (s2d_multi_set_stall_timeout): then the handle must be re-created. */
 #define S2D_MULTI_SHARE_GPU 0x1u  /* rehearsal on a box with fewer GPUs than ranks: all ranks on devices[0]; peer copies
                                    * become device copies, the all-reduce is staged through pinned host memory in rank
                                    * order (RCCL takes one rank per GPU) */

@@ -76,6 +76,12 @@ void sim_stream_destroy(hipStream_t s);
 void sim_enqueue(hipStream_t s, std::function<void()> op); // runs on the stream's thread, in order
 int sim_device_count();
 void sim_set_device_count(int n);
+// failure injection (multi_sim_main.cpp): s2d_forward_backward of the context on `device` fails at `iteration` (< 0: never);
+// the `call`-th ncclAllReduce submitted for rank `rank` returns an error (< 0: never)
+void sim_fail_forward_backward(int device, int iteration);
+void sim_fail_allreduce(int rank, long long call);
+int sim_forward_backward_fails(int device, int iteration);
+int sim_allreduce_fails(int rank);
 // counters for the test's own assertions
 struct SimCounters {
     unsigned long long ops, peer_copies, event_waits, event_records;

@@ -156,6 +156,44 @@ static void stalled_rank(int world, uint32_t flags, int stall_rank, int at_itera
            g_failures == before ? "ok" : "NOT ok", world, (flags & S2D_MULTI_REPLICATED) ? "replicated, RCCL" : "ownership", stall_rank, at_iteration, secs, msg.c_str());
 }
 
+// One rank's launch fails (ownership and RCCL) or its all-reduce submission does: the call must return THAT rank's error --
+// not a timeout of the others --, quickly; with RCCL the others' communicators are aborted (they sit in collectives the failed
+// rank never joins) and the handle is dead; a slab-ownership handle stays usable after a restart.
+static void failing_rank(int world, uint32_t flags, int bad_rank, int at_iteration, bool in_allreduce)
+{
+    const int W = 64, H = 32 * world, n = 40 * world;
+    const int before = g_failures;
+    s2d_multi* m = make(world, W, H, n, flags);
+    EXPECT(s2d_multi_set_target_synthetic(m) == S2D_OK && s2d_multi_init_splats(m) == S2D_OK, "set up");
+    EXPECT(s2d_multi_set_stall_timeout(m, 3000) == S2D_OK, "set_stall_timeout");
+    if (in_allreduce) sim_fail_allreduce(bad_rank, at_iteration);
+    else sim_fail_forward_backward(bad_rank, at_iteration);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = s2d_multi_step(m, 150, 0, nullptr);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const std::string msg = s2d_multi_last_error(m);
+    sim_fail_allreduce(-1, -1);
+    sim_fail_forward_backward(-1, -1);
+    char want[32];
+    snprintf(want, sizeof(want), "on rank %d", bad_rank);
+    EXPECT(rc == S2D_E_HIP && msg.find(want) != std::string::npos, "the failing rank's own error is reported: %d %s", rc, msg.c_str());
+    EXPECT(msg.find(in_allreduce ? "ncclAllReduce failed" : "simulated device fault") != std::string::npos, "... with its cause: %s", msg.c_str());
+    EXPECT(secs < 2.5, "without waiting for a stall limit: %.2f s", secs);
+    const int again = s2d_multi_step(m, 1, 0, nullptr); // refused either way: the ranks stand at different iterations
+    EXPECT(again == S2D_E_STATE, "a step right after a failed one is refused: %d %s", again, s2d_multi_last_error(m));
+    if (flags & S2D_MULTI_REPLICATED) {
+        EXPECT(std::string(s2d_multi_last_error(m)).find("create a new one") != std::string::npos, "RCCL: the communicators are gone: %s",
+               s2d_multi_last_error(m));
+    } else {
+        EXPECT(s2d_multi_init_splats(m) == S2D_OK && s2d_multi_step(m, 70, 0, nullptr) == S2D_OK, "ownership: usable after a restart: %s",
+               s2d_multi_last_error(m));
+    }
+    s2d_multi_destroy(m);
+    printf("%s: %d ranks (%s), rank %d fails in its %s at iteration %d -> %s after %.2f s\n", g_failures == before ? "ok" : "NOT ok", world,
+           (flags & S2D_MULTI_REPLICATED) ? "replicated, RCCL" : "ownership", bad_rank, in_allreduce ? "all-reduce submission" : "raster launch",
+           at_iteration, msg.c_str(), secs);
+}
+
 static void nonfinite(int world, uint32_t flags)
 {
     const int W = 64, H = 32 * world, n = 40 * world;
@@ -188,6 +226,9 @@ int main(int argc, char** argv)
     stalled_rank(2, 0, 1, 3, 10);
     stalled_rank(3, S2D_MULTI_REPLICATED, 1, 5, 20);   // RCCL: the others sit in an all-reduce it never joins
     stalled_rank(8, S2D_MULTI_REPLICATED, 7, 130, 200);
+    failing_rank(4, 0, 1, 37, false);
+    failing_rank(4, S2D_MULTI_REPLICATED, 2, 9, false);
+    failing_rank(3, S2D_MULTI_REPLICATED, 0, 70, true);
     nonfinite(4, 0);
     nonfinite(4, S2D_MULTI_REPLICATED);
     const SimCounters c = sim_counters();

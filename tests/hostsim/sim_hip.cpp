@@ -87,6 +87,34 @@ void sim_enqueue(hipStream_t s, std::function<void()> op)
     s->cv.notify_all();
 }
 
+namespace {
+std::atomic<int> g_fail_dev{-1}, g_fail_iter{-1}, g_fail_ar_rank{-1};
+std::atomic<long long> g_fail_ar_call{-1};
+std::atomic<long long> g_ar_calls[64];
+} // namespace
+
+void sim_fail_forward_backward(int device, int iteration)
+{
+    g_fail_dev.store(device);
+    g_fail_iter.store(iteration);
+}
+
+void sim_fail_allreduce(int rank, long long call)
+{
+    for (auto& c : g_ar_calls) c.store(0);
+    g_fail_ar_rank.store(rank);
+    g_fail_ar_call.store(call);
+}
+
+int sim_forward_backward_fails(int device, int iteration) { return device == g_fail_dev.load() && iteration == g_fail_iter.load(); }
+
+int sim_allreduce_fails(int rank)
+{
+    if (rank < 0 || rank >= 64) return 0;
+    const long long k = g_ar_calls[rank].fetch_add(1);
+    return rank == g_fail_ar_rank.load() && k == g_fail_ar_call.load();
+}
+
 int sim_device_count() { return g_devices.load(); }
 void sim_set_device_count(int n) { g_devices.store(n); }
 SimCounters sim_counters() { return SimCounters{g_ops.load(), g_peer.load(), g_waits.load(), g_records.load()}; }

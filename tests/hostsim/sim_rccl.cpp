@@ -79,6 +79,7 @@ ncclResult_t ncclAllReduce(const void* send, void* recv, size_t count, ncclDataT
         fprintf(stderr, "SIM RCCL: ncclAllReduce submitted on an aborted / destroyed communicator (a use-after-free on real RCCL)\n");
         abort();
     }
+    if (sim_allreduce_fails(comm->rank)) return ncclUnhandledCudaError; // injected: this rank's share is never queued
     sim_enqueue(stream, [=] {
         SimGroup* g = comm->group;
         std::unique_lock<std::mutex> lk(g->m);

@@ -8,7 +8,8 @@ hipStreamWaitEvent = a wait for the record that was the latest when it was calle
 simulated on the CPU oracle.  tests/hostsim/multi_sim_main.cpp then runs 2 / 4 / 8 rank threads through 230 iterations with
 three hold-set refreshes, a get_splats / set_splats in the middle and ranks slowed down at random; slab ownership and
 replicated state (through the simulated RCCL) must agree bit for bit; a rank that stops answering must give S2D_E_STATE
-naming it (both schemes); a non-finite stop must be reported and survived.  ThreadSanitizer must stay silent throughout.
+naming it (both schemes); a rank whose launch or all-reduce submission fails must be reported with ITS error, at once, and a
+step right after it refused; a non-finite stop must be reported and survived.  ThreadSanitizer must stay silent throughout.
 
 Test infrastructure only: nothing here is a CPU path of the product.
 """
@@ -54,6 +55,7 @@ def test_multi_device_host_protocol_is_race_free_and_fails_informatively(sim):
     for world in (2, 4, 8):
         assert any(ln.startswith("ok: %d ranks, 230 iterations, ownership == replicated bit for bit" % world) for ln in lines), report
     assert sum("stops answering" in ln and "S2D_E_STATE" in ln for ln in lines) == 4, report
+    assert sum(ln.startswith("ok:") and "fails in its" in ln for ln in lines) == 3, report   # a rank's own error, not the others' timeouts
     assert sum("non-finite stop reported and survived" in ln for ln in lines) == 2, report
     # the simulated runtime really was exercised: peer copies, event waits
     tail = [ln for ln in lines if ln.startswith("simulated runtime:")][0].split()
