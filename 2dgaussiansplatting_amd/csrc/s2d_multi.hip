@@ -100,13 +100,17 @@ struct Barrier {
     std::atomic<bool> broken{false};
     std::atomic<bool> timed_out{false};
     std::atomic<int> timeout_ms{0}; // 0: wait without bound
-    void wait()
+    uint64_t here = 0;              // bit r: rank r is waiting in the current generation
+    std::atomic<uint64_t> missing{0}; // when a wait timed out: the ranks that had not arrived at that moment
+    void wait(int rank)
     {
         std::unique_lock<std::mutex> lk(m);
         if (broken) return;
         const int gen = generation;
+        here |= 1ull << (rank & 63);
         if (++waiting == n) {
             waiting = 0;
+            here = 0;
             generation++;
             cv.notify_all();
             return;
@@ -116,6 +120,7 @@ struct Barrier {
         if (ms <= 0) {
             cv.wait(lk, ready);
         } else if (!cv.wait_for(lk, std::chrono::milliseconds(ms), ready)) {
+            missing = ~here & ((n >= 64) ? ~0ull : ((1ull << n) - 1ull)); // who is not here NOW (they may show up a moment later)
             timed_out = true;
             broken = true;
             cv.notify_all();
@@ -133,6 +138,8 @@ struct Barrier {
         broken = false;
         timed_out = false;
         waiting = 0;
+        here = 0;
+        missing = 0;
     }
 };
 
@@ -372,24 +379,27 @@ inline bool stopped(s2d_multi* m, int rank)
 }
 
 // Barrier of the rank threads; false once some rank has failed (the caller stops) or did not arrive in time.
-bool meet(s2d_multi* m)
-{
-    m->barrier.wait();
-    return !m->barrier.broken;
-}
 
 // meet() for a rank: S2D_OK, kStopped (somebody else failed), or S2D_E_STATE when the wait itself ran out -- some rank
 // never arrived; the first rank to notice reports it.
 int meet_rank(s2d_multi* m, int r, const char* where)
 {
-    m->barrier.wait();
+    m->barrier.wait(r);
     if (!m->barrier.broken) return S2D_OK;
     if (m->barrier.timed_out.exchange(false)) {
-        const std::string missing = phase_table(m);
+        const std::string table = phase_table(m);
+        std::string who;
+        const uint64_t missing = m->barrier.missing.load();
+        for (int q = 0; q < m->world; q++)
+            if ((missing >> q) & 1ull) {
+                char one[48];
+                snprintf(one, sizeof(one), "%srank %d (device %d)", who.empty() ? "" : ", ", q, m->devices[(size_t)q]);
+                who += one;
+            }
         m->timed_out.store(true);
         stop_everybody(m, r);
-        return rank_fail(m, r, S2D_E_STATE, "a rank did not reach the rendezvous of the %s within %d ms (%s)", where,
-                         m->barrier.timeout_ms.load(), missing.c_str());
+        return rank_fail(m, r, S2D_E_STATE, "%s did not reach the rendezvous of the %s within %d ms (the ranks now: %s)", who.c_str(), where,
+                         m->barrier.timeout_ms.load(), table.c_str());
     }
     (void)stopped(m, r);
     return kStopped;

@@ -80,6 +80,11 @@ void sim_set_device_count(int n);
 // the `call`-th ncclAllReduce submitted for rank `rank` returns an error (< 0: never)
 void sim_fail_forward_backward(int device, int iteration);
 void sim_fail_allreduce(int rank, long long call);
+// s2d_forward_backward of the context on `device` does not RETURN at `iteration` (a runtime call that hangs) until
+// sim_release_blocked() is called
+void sim_block_forward_backward(int device, int iteration);
+void sim_release_blocked();
+void sim_maybe_block(int device, int iteration);
 int sim_forward_backward_fails(int device, int iteration);
 int sim_allreduce_fails(int rank);
 // counters for the test's own assertions

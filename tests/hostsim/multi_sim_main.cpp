@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/splat2d.h"
@@ -49,7 +50,7 @@ static s2d_multi* make(int world, int W, int H, int n, uint32_t flags)
 {
     const s2d_config cfg = config(W, H, n);
     std::vector<int32_t> dev((size_t)world);
-    for (int r = 0; r < world; r++) dev[(size_t)r] = r;
+    for (int r = 0; r < world; r++) dev[(size_t)r] = (flags & S2D_MULTI_SHARE_GPU) ? 0 : r;
     s2d_multi* m = nullptr;
     const int rc = s2d_multi_create(&cfg, dev.data(), world, flags, &m);
     if (rc != S2D_OK) {
@@ -97,12 +98,12 @@ static Run train(int world, int W, int H, int n, uint32_t flags, bool jitter)
     return out;
 }
 
-static void compare_schemes(int world)
+static void compare_schemes(int world, uint32_t extra = 0)
 {
     const int W = 64, H = 32 * world, n = 60 * world;
     const int before = g_failures;
-    const Run own = train(world, W, H, n, 0, true);
-    const Run rep = train(world, W, H, n, S2D_MULTI_REPLICATED, false);
+    const Run own = train(world, W, H, n, extra, true);
+    const Run rep = train(world, W, H, n, extra | S2D_MULTI_REPLICATED, false);
     EXPECT(own.trace.size() == 230 && rep.trace.size() == 230, "trace lengths %zu %zu", own.trace.size(), rep.trace.size());
     EXPECT(own.info[0] == 1 && rep.info[0] == 2, "schemes %lld %lld", (long long)own.info[0], (long long)rep.info[0]);
     // (two slabs of 32 rows: every splat is within reach + margin of both -- from four ranks on, no rank holds everything)
@@ -119,9 +120,10 @@ static void compare_schemes(int world)
     for (size_t k = 0; k < own.adams.size() * 18; k++) bad += !(a[k] == b[k]);
     EXPECT(bad == 0, "%zu Adam moments differ (%d ranks)", bad, world);
     EXPECT(std::isfinite(own.trace.back()) && own.trace.back() < own.trace.front(), "the run trains: %g -> %g", own.trace.front(), own.trace.back());
-    printf("%s: %d ranks, 230 iterations, ownership == replicated bit for bit (mse %.4f -> %.4f, %lld rows swapped per iteration, %lld hand-overs)\n",
-           g_failures == before ? "ok" : "NOT ok", world, own.trace.front(), own.trace.back(), (long long)own.info[1], (long long)own.info[2]);
-    if (world == 2) { // ... and both follow one context on the whole image (only the order of the gradient sums differs)
+    printf("%s: %d ranks%s, 230 iterations, ownership == replicated bit for bit (mse %.4f -> %.4f, %lld rows swapped per iteration, %lld hand-overs)\n",
+           g_failures == before ? "ok" : "NOT ok", world, (extra & S2D_MULTI_SHARE_GPU) ? " sharing one device (device copies, host-staged sums)" : "",
+           own.trace.front(), own.trace.back(), (long long)own.info[1], (long long)own.info[2]);
+    if (world == 2 && !extra) { // ... and both follow one context on the whole image (only the order of the gradient sums differs)
         const Run one = train(1, W, H, n, 0, false);
         double worst = 0.0;
         for (size_t k = 0; k < one.trace.size() && k < own.trace.size(); k++)
@@ -137,6 +139,7 @@ static void stalled_rank(int world, uint32_t flags, int stall_rank, int at_itera
 {
     const int W = 64, H = 32 * world, n = 40 * world;
     const int before = g_failures;
+    char want[64];
     s2d_multi* m = make(world, W, H, n, flags);
     EXPECT(s2d_multi_set_target_synthetic(m) == S2D_OK && s2d_multi_init_splats(m) == S2D_OK, "set up");
     EXPECT(s2d_multi_set_stall_timeout(m, 300) == S2D_OK, "set_stall_timeout");
@@ -146,8 +149,10 @@ static void stalled_rank(int world, uint32_t flags, int stall_rank, int at_itera
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     const std::string msg = s2d_multi_last_error(m);
     EXPECT(rc == S2D_E_STATE, "a stalled rank gives S2D_E_STATE, got %d (%s)", rc, msg.c_str());
-    char want[48];
-    snprintf(want, sizeof(want), (flags & S2D_MULTI_REPLICATED) ? "furthest behind: rank %d" : "rank %d (device %d) stopped answering", stall_rank, stall_rank);
+    const int dev = (flags & S2D_MULTI_SHARE_GPU) ? 0 : stall_rank;
+    if ((flags & S2D_MULTI_REPLICATED) && (flags & S2D_MULTI_SHARE_GPU)) snprintf(want, sizeof(want), "rank %d (device %d) did not reach the rendezvous", stall_rank, dev);
+    else if (flags & S2D_MULTI_REPLICATED) snprintf(want, sizeof(want), "furthest behind: rank %d", stall_rank);
+    else snprintf(want, sizeof(want), "rank %d (device %d) stopped answering", stall_rank, dev);
     EXPECT(msg.find(want) != std::string::npos, "the report names the rank: %s", msg.c_str());
     EXPECT(secs < 20.0, "the call came back after %.1f s", secs);
     EXPECT(s2d_multi_step(m, 1, 0, nullptr) == S2D_E_STATE, "a handle whose ranks disagree refuses further steps");
@@ -194,6 +199,35 @@ static void failing_rank(int world, uint32_t flags, int bad_rank, int at_iterati
            at_iteration, msg.c_str(), secs);
 }
 
+// A rank sits inside a runtime call that never returns: it cannot answer the stop.  The caller's watchdog (run_command) must
+// notice that nobody moves, stop the others, give up on the one that does not come back, and return; the handle is then
+// abandoned (destroy returns at once, nothing of it is freed under the sleeping thread).
+static void rank_inside_a_call_that_never_returns(int world, uint32_t flags, int bad_rank, int at_iteration)
+{
+    const int W = 64, H = 32 * world, n = 40 * world;
+    const int before = g_failures;
+    s2d_multi* m = make(world, W, H, n, flags);
+    EXPECT(s2d_multi_set_target_synthetic(m) == S2D_OK && s2d_multi_init_splats(m) == S2D_OK, "set up");
+    EXPECT(s2d_multi_set_stall_timeout(m, 500) == S2D_OK, "set_stall_timeout");
+    sim_block_forward_backward(bad_rank, at_iteration);
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = s2d_multi_step(m, 12, 0, nullptr);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    const std::string msg = s2d_multi_last_error(m);
+    char want[48];
+    snprintf(want, sizeof(want), "rank %d (device %d) at 'raster launch'", bad_rank, bad_rank);
+    EXPECT(rc == S2D_E_STATE && msg.find("abandoned") != std::string::npos && msg.find(want) != std::string::npos, "%d %s", rc, msg.c_str());
+    EXPECT(secs < 15.0, "the call came back after %.1f s", secs);
+    EXPECT(s2d_multi_step(m, 1, 0, nullptr) == S2D_E_STATE, "an abandoned handle refuses");
+    const auto t1 = std::chrono::steady_clock::now();
+    s2d_multi_destroy(m);
+    EXPECT(std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() < 1.0, "destroy of an abandoned handle returns at once");
+    sim_release_blocked(); // let the sleeping thread run out (it finds the stop and leaves; the abandoned handle is still there)
+    std::this_thread::sleep_for(std::chrono::milliseconds(300));
+    printf("%s: %d ranks (%s), rank %d inside a call that never returns -> abandoned after %.2f s: %s\n", g_failures == before ? "ok" : "NOT ok", world,
+           (flags & S2D_MULTI_REPLICATED) ? "replicated, RCCL" : "ownership", bad_rank, secs, msg.c_str());
+}
+
 static void nonfinite(int world, uint32_t flags)
 {
     const int W = 64, H = 32 * world, n = 40 * world;
@@ -222,10 +256,14 @@ int main(int argc, char** argv)
         if (quick && world != 4) continue;
         compare_schemes(world);
     }
+    compare_schemes(3, S2D_MULTI_SHARE_GPU);          // the rehearsal mode of one-GPU boxes: device copies, host-staged sums
     stalled_rank(4, 0, 2, 70, 100);                    // ownership: the neighbours wait for its exchange
     stalled_rank(2, 0, 1, 3, 10);
     stalled_rank(3, S2D_MULTI_REPLICATED, 1, 5, 20);   // RCCL: the others sit in an all-reduce it never joins
     stalled_rank(8, S2D_MULTI_REPLICATED, 7, 130, 200);
+    stalled_rank(3, S2D_MULTI_REPLICATED | S2D_MULTI_SHARE_GPU, 2, 4, 12); // host-staged sums: the others wait at its rendezvous
+    rank_inside_a_call_that_never_returns(3, 0, 1, 5);
+    rank_inside_a_call_that_never_returns(4, S2D_MULTI_REPLICATED, 3, 6);
     failing_rank(4, 0, 1, 37, false);
     failing_rank(4, S2D_MULTI_REPLICATED, 2, 9, false);
     failing_rank(3, S2D_MULTI_REPLICATED, 0, 70, true);

@@ -227,6 +227,7 @@ int s2d_forward_backward(s2d_ctx* c, uint32_t)
         return S2D_E_STATE;
     }
     const int it = c->iterations;
+    sim_maybe_block(c->device, it); // injected: a runtime call that does not return
     if (sim_forward_backward_fails(c->device, it)) { // injected: a launch that the runtime refuses on this device only
         snprintf(c->err, sizeof(c->err), "hipLaunchKernel failed: simulated device fault (device %d, iteration %d)", c->device, it);
         return S2D_E_HIP;

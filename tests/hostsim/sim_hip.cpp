@@ -106,6 +106,38 @@ void sim_fail_allreduce(int rank, long long call)
     g_fail_ar_call.store(call);
 }
 
+namespace {
+std::mutex g_block_m;
+std::condition_variable g_block_cv;
+int g_block_dev = -1, g_block_iter = -1;
+bool g_block_released = false;
+} // namespace
+
+void sim_block_forward_backward(int device, int iteration)
+{
+    std::lock_guard<std::mutex> lk(g_block_m);
+    g_block_dev = device;
+    g_block_iter = iteration;
+    g_block_released = false;
+}
+
+void sim_release_blocked()
+{
+    {
+        std::lock_guard<std::mutex> lk(g_block_m);
+        g_block_released = true;
+        g_block_dev = g_block_iter = -1;
+    }
+    g_block_cv.notify_all();
+}
+
+void sim_maybe_block(int device, int iteration)
+{
+    std::unique_lock<std::mutex> lk(g_block_m);
+    if (device != g_block_dev || iteration != g_block_iter) return;
+    g_block_cv.wait(lk, [] { return g_block_released; });
+}
+
 int sim_forward_backward_fails(int device, int iteration) { return device == g_fail_dev.load() && iteration == g_fail_iter.load(); }
 
 int sim_allreduce_fails(int rank)

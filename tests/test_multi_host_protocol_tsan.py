@@ -9,7 +9,8 @@ simulated on the CPU oracle.  tests/hostsim/multi_sim_main.cpp then runs 2 / 4 /
 three hold-set refreshes, a get_splats / set_splats in the middle and ranks slowed down at random; slab ownership and
 replicated state (through the simulated RCCL) must agree bit for bit; a rank that stops answering must give S2D_E_STATE
 naming it (both schemes); a rank whose launch or all-reduce submission fails must be reported with ITS error, at once, and a
-step right after it refused; a non-finite stop must be reported and survived.  ThreadSanitizer must stay silent throughout.
+step right after it refused; a rank inside a runtime call that never returns must be given up on by the caller's watchdog
+(the handle abandoned, not freed); a non-finite stop must be reported and survived.  ThreadSanitizer must stay silent throughout.
 
 Test infrastructure only: nothing here is a CPU path of the product.
 """
@@ -54,7 +55,9 @@ def test_multi_device_host_protocol_is_race_free_and_fails_informatively(sim):
     assert not [ln for ln in lines if ln.startswith("NOT ok")], report
     for world in (2, 4, 8):
         assert any(ln.startswith("ok: %d ranks, 230 iterations, ownership == replicated bit for bit" % world) for ln in lines), report
-    assert sum("stops answering" in ln and "S2D_E_STATE" in ln for ln in lines) == 4, report
+    assert any(ln.startswith("ok: 3 ranks sharing one device") for ln in lines), report       # the one-GPU rehearsal mode
+    assert sum("stops answering" in ln and "S2D_E_STATE" in ln for ln in lines) == 5, report
+    assert sum(ln.startswith("ok:") and "inside a call that never returns -> abandoned" in ln for ln in lines) == 2, report
     assert sum(ln.startswith("ok:") and "fails in its" in ln for ln in lines) == 3, report   # a rank's own error, not the others' timeouts
     assert sum("non-finite stop reported and survived" in ln for ln in lines) == 2, report
     # the simulated runtime really was exercised: peer copies, event waits
