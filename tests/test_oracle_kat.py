@@ -159,3 +159,21 @@ def test_adam_quotient_precision_choice_is_immaterial():
     print("\n[adam] double vs float quotient: max rel MSE difference over 100 iterations %.2e (at it %d); it 99: %.4f vs %.4f"
           % (rel.max(), rel.argmax(), t64[99], t32[99]))
     assert rel.max() <= 5e-3
+
+
+def test_overlay_vertices_against_committed_fixture():
+    """The oracle's restatement of the debug drawing (main.cpp:419-477, s2do_overlay_vertices) reproduces the committed vertex
+    lists of the scene as shipped at init() and after 10 iterations (tools/make_oracle_golden.py): guards the restatement --
+    which the host program's overlay is compared with bit for bit -- against accidental edits.  (The fixture is the oracle's own
+    output: the reference holds none for this.)"""
+    import hashlib
+    z = np.load(os.path.join(O.GOLDEN, "overlay_vertices_mini_1024.npz"))
+    tgt = O.target_rgba32f(O.load_s2di(os.path.join(O.GOLDEN, "squirrel_cls_mini_268x213.s2di")))
+    o = O.OracleTrainer(tgt, 1024)
+    for tag in ("it0", "it10"):
+        xyz, rgb = O.overlay_vertices(o.splats)
+        k = 3 * O.OVERLAY_VERTICES
+        assert xyz[:k].tobytes() == z["xyz_first3_" + tag].tobytes() and rgb[:k].tobytes() == z["rgb_first3_" + tag].tobytes(), tag
+        assert hashlib.sha256(xyz.tobytes() + rgb.tobytes()).hexdigest() == str(z["sha256_" + tag]), tag
+        for _ in range(10):
+            o.step()

@@ -27,3 +27,18 @@ np.savez_compressed(out, **state, mse_trace_0_4=np.array(trace), image_sha256=np
                     grads_exact_sum=dsum, grads_abs_sum=dabs.astype(np.float32), active_pairs=np.uint64(c.active), mse=np.float64(mse),
                     splats_after_step=o.splats.copy(), mse_of_step=np.float64(mse_step))
 print(out, os.path.getsize(out), "bytes; mse", mse, "active", c.active)
+
+# The overlay's vertex list (main.cpp:419-477, oracle s2do_overlay_vertices) of the scene as shipped (N = 1024) at init() and
+# after 10 oracle iterations: the first three splats' 46 vertices verbatim, and a sha256 of all of them.
+o = O.OracleTrainer(tgt, 1024)
+ov = {}
+for tag in ("it0", "it10"):
+    xyz, rgb = O.overlay_vertices(o.splats)
+    ov["xyz_first3_" + tag] = xyz[:3 * O.OVERLAY_VERTICES].copy()
+    ov["rgb_first3_" + tag] = rgb[:3 * O.OVERLAY_VERTICES].copy()
+    ov["sha256_" + tag] = np.array(hashlib.sha256(xyz.tobytes() + rgb.tobytes()).hexdigest())
+    for _ in range(10):
+        o.step()
+out = os.path.join(O.GOLDEN, "overlay_vertices_mini_1024.npz")
+np.savez_compressed(out, **ov)
+print(out, os.path.getsize(out), "bytes")
