@@ -22,7 +22,13 @@ HIP_HEADERS = ["s2d_device.h", "s2d_math.h"]
 
 # -ffp-contract=off: the kernels keep the reference's evaluation order (no FMA contraction) wherever a
 # discrete decision or the framebuffer depends on it; fp32 divide/sqrt stay correctly rounded (hipcc default).
+# -amdgpu-atomic-optimizer-strategy=None: LLVM rewrites an atomic whose address is wave-uniform into a reduction over the active
+# lanes (a scalar s_ff1 / v_readlane loop, v_mbcnt, a second exec switch) followed by one lane's atomic.  The backward blend adds
+# the ninth gradient from ONE lane per executed (wave, entry): the rewrite put ~10 vector and ~12 scalar instructions around a
+# single ds_add_f32, two thirds of what that gradient cost (profiles/r04/ab_ninth_gradient_atomic.txt).  The counters that do
+# add from all lanes to one address are diagnostics (S2D_CFG_COUNT_PAIRS).
 HIPCC_FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared",
+               "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
                "-Wall", "-Wno-unused-function", "-pthread", "-ldl"]
 
 

@@ -105,6 +105,15 @@ __device__ __forceinline__ f2 mk2(float a, float b)
     return r;
 }
 
+// Diagnostic counters (S2D_CFG_COUNT_PAIRS): a per-lane count is summed over the wave first and added by one lane (the build
+// switches LLVM's atomic optimizer off, _build.py: nothing does this behind our back any more).
+__device__ __forceinline__ void count_add(unsigned long long* counter, unsigned long long v, int lane)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_down(v, d, 64);
+    if (lane == 0) atomicAdd(counter, v);
+}
+
 // Pixel of thread tid inside the tile.
 __device__ __forceinline__ void pixel_of_thread(int tid, int* lx, int* ly)
 {
@@ -290,12 +299,12 @@ __device__ __forceinline__ void forward_tile(FwdShared& s, const TileCtx& c, con
     }
     if (CHUNK) *T_io = T;
     if (COUNT) {
-        atomicAdd(&counters->fwd_visited, n_vis);
-        atomicAdd(&counters->fwd_active, n_act);
+        count_add(&counters->fwd_visited, n_vis, lane);
+        count_add(&counters->fwd_active, n_act, lane);
         if (tid == 0) atomicAdd(&counters->fwd_staged, n_staged);
         if (lane == 0) atomicAdd(&counters->fwd_wave_execs, n_exec);
-        atomicAdd(&counters->fwd_rows_hit, n_rows_hit);
-        atomicAdd(&counters->fwd_staged_hit, n_staged_hit);
+        count_add(&counters->fwd_rows_hit, n_rows_hit, lane);
+        count_add(&counters->fwd_staged_hit, n_staged_hit, lane);
     }
 }
 
@@ -496,7 +505,10 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
     const int tid = c.tid, lane = c.lane, w = c.w;
     const bool inside = c.inside;
     const f2 pxy = c.pxy;
-    const int part_slot = lane >> 3; // after wave_sum8_lds the 8-lane group holds the total of component lane >> 3
+    // after wave_sum8_lds the 8-lane group holds the total of component lane >> 3, and lane 63 the ninth sum (slot 8)
+    const bool op_lane = NEED_OP && !DET && lane == 63;
+    const int part_slot = op_lane ? 8 : lane >> 3;
+    const bool adds = (lane & 7) == 0 || op_lane;
     const float dLr = fin.x - ref.x, dLg = fin.y - ref.y, dLb = fin.z - ref.z; // dL_dC, main.cpp:616
     const f2 dLrg = mk2(dLr, dLg), fin_rg = mk2(fin.x, fin.y);
 
@@ -667,8 +679,8 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
                     if ((lane & 7) == 0) part[pe + part_slot] = tot;
                     if (NEED_OP && lane == 63) part[pe + 8] = g_op;
                 } else {
-                    if ((lane & 7) == 0) __hip_atomic_fetch_add(part + (pe + part_slot), tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    if (NEED_OP && lane == 63) __hip_atomic_fetch_add(part + (pe + 8), g_op, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const float val = op_lane ? g_op : tot; // one LDS instruction for the eight totals and the ninth sum
+                    if (adds) __hip_atomic_fetch_add(part + (pe + part_slot), val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
@@ -711,8 +723,8 @@ __device__ __forceinline__ void backward_tile(BwdShared<DET>& s, const TileCtx& 
     }
     if (CHUNK) *state_io = make_float4(crg.x, crg.y, cb, T);
     if (COUNT) {
-        atomicAdd(&counters->bwd_visited, n_vis);
-        atomicAdd(&counters->bwd_active, n_act);
+        count_add(&counters->bwd_visited, n_vis, lane);
+        count_add(&counters->bwd_active, n_act, lane);
         if (tid == 0) atomicAdd(&counters->bwd_staged, n_staged);
         if (lane == 0) atomicAdd(&counters->bwd_wave_execs, n_exec);
     }
