@@ -6,10 +6,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 S2D = importlib.import_module("2dgaussiansplatting_amd")
-for W, H, n, steps, kw in ((268, 213, 2000, 20000, {}), (4096, 4096, 1000000, 3000, {}), (4096, 4096, 1000000, 1000, {"deterministic": True}),
-                            (8192, 8192, 4000000, 300, {"fp16_images": True})):
+for W, H, n, steps, kw in ((268, 213, 2000, 20000, {}), (4096, 4096, 1000000, 3000, {}), (4096, 4096, 1000000, 2000, {"opacity": True}),
+                            (4096, 4096, 1000000, 1000, {"deterministic": True}), (8192, 8192, 4000000, 300, {"fp16_images": True})):
+    opacity = kw.pop("opacity", False)   # "Optimize opacity" on: the nine-gradient kernel, opacity trained
     with S2D.Trainer(W, H, n, **kw) as t:
         t.lean_backward = True
+        t.optimize_opacity = opacity
+        if opacity:
+            kw = dict(kw, optimize_opacity=True)
         t.set_target_synthetic(); t.init()
         t0 = time.perf_counter()
         done = 0
