@@ -49,6 +49,9 @@ struct Options {
     std::string load_ckpt, save_ckpt; // the five objects of main.cpp:272-278: splats, splatAdams, beta1t, beta2t, iterations
     int device = 0;
     int rebin_interval = 0;
+    float lr = 0.0f;            // --lr: trainingRate, main.cpp:715 (0 = the reference's 0.05)
+    bool deterministic = false; // --deterministic: bitwise reproducible gradient sums (S2D_CFG_DETERMINISTIC)
+    int stall_ms = -1;          // --stall-timeout-ms (multi-device handle): how long a rank may not answer before the step fails
     int gpus = 1;               // --gpus N: devices device .. device + N - 1, one row slab each, RCCL all-reduce of the gradients
     bool share_gpu = false;     // --share-gpu: all N ranks on --device (rehearsal on a box with fewer GPUs than ranks)
     bool replicated = false;    // --exchange dense: replicated state + RCCL all-reduce of all gradients (default: slab ownership)
@@ -71,7 +74,8 @@ int usage()
                  "                     [--overlay file [--overlay-scale S] [--overlay-stride K] [--overlay-vertices file]]\n"
                  "       splat2d_train --convert in.(s2di|ppm|png|jpg) out.(s2di|ppm|png)\n"
                  "                     [--load-checkpoint file] [--save-checkpoint file]\n"
-                 "                     [--device D] [--gpus N [--exchange halo|dense] [--share-gpu]] [--rebin-interval R] [--quiet]\n");
+                 "                     [--lr RATE] [--deterministic] [--device D] [--gpus N [--exchange halo|dense] [--share-gpu]\n"
+                 "                     [--stall-timeout-ms MS]] [--rebin-interval R] [--quiet]\n");
     return 2;
 }
 
@@ -91,6 +95,8 @@ struct Session {
         cfg.height = H;
         cfg.n_splats = o.n_splats; // int NSplat = 1024; main.cpp:271
         cfg.rebin_interval = o.rebin_interval;
+        cfg.training_rate = o.lr;
+        if (o.deterministic) cfg.flags |= S2D_CFG_DETERMINISTIC;
         is_multi = o.gpus > 1 || std::getenv("S2D_TRAIN_FORCE_MULTI"); // (the variable sends --gpus 1 through the handle)
         if (!is_multi) {
             cfg.device = o.device;
@@ -192,6 +198,9 @@ int main(int argc, char** argv)
         }
         else if (a == "--rebin-interval") o.rebin_interval = std::atoi(next("--rebin-interval"));
         else if (a == "--quiet") o.quiet = true;
+        else if (a == "--lr") o.lr = (float)std::atof(next("--lr"));
+        else if (a == "--deterministic") o.deterministic = true;
+        else if (a == "--stall-timeout-ms") o.stall_ms = std::atoi(next("--stall-timeout-ms"));
         else return usage();
     }
     if (!o.convert_in.empty()) { // file conversion between .s2di / .ppm / .png; touches no GPU
@@ -224,6 +233,7 @@ int main(int argc, char** argv)
     if (o.gpus < 1) return usage();
     Session S;
     CK(S.create(o, W, H));
+    if (S.is_multi && o.stall_ms >= 0) CK(s2d_multi_set_stall_timeout(S.multi, o.stall_ms));
     if (S.is_multi) { // which GPU runs which rows (stderr: stdout is the reference's trace)
         for (int r = 0; r < s2d_multi_device_count(S.multi); r++) {
             int32_t dev = 0, r0 = 0, r1 = 0;

@@ -941,6 +941,28 @@ def test_against_committed_oracle_golden():
     assert (np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max() <= REL
 
 
+def test_cpp_host_learning_rate_and_deterministic_flags():
+    """lr as a flag of the host program (trainingRate, main.cpp:715).  splat2d_train --lr 0.02 follows the
+    oracle's loop run with that rate; --deterministic runs are bitwise reproducible."""
+    import subprocess
+    exe = S2D._build.build_host_program()
+    tgt = mini_target()
+    o = O.OracleTrainer(tgt, 1024)
+    want = []
+    for _ in range(6):
+        o.forward()
+        want.append(o.mse())
+        o.backward()
+        assert o.adam(np.float32(0.02)) == 0
+    runs = [subprocess.run([exe, "--image", MINI, "--splats", "1024", "--iters", "6", "--lr", "0.02", "--deterministic"], capture_output=True,
+                           text=True, timeout=300) for _ in range(2)]
+    assert all(r.returncode == 0 for r in runs), runs[0].stderr[-1500:]
+    got = [float(ln.split("mse")[1]) for ln in runs[0].stdout.strip().splitlines()]
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=5e-5)   # (%.4f prints)
+    assert abs(got[0] - 5934.9042) < 1e-3 and got[1] > 5200      # a 0.02 step lowers the MSE less than the 0.05 one (4659.3)
+    assert runs[0].stdout == runs[1].stdout
+
+
 def test_cpp_host_png_target_and_overlay(tmp_path):
     """A PNG target gives the same trace as the raw fixture; --overlay writes the reference's splat debug drawing
     (main.cpp:441-485) as an image."""
