@@ -84,3 +84,18 @@ def test_the_harness_sees_a_seeded_race(sim, tmp_path):
                            "-ldl", "-lm", "-Wl,--disable-new-dtags", "-Wl,-rpath," + build])
     p = _run(exe, "quick")
     assert "WARNING: ThreadSanitizer: data race" in p.stderr and "s2d_rows_gather" in p.stderr, p.stdout + p.stderr[-3000:]
+
+
+def test_multi_device_host_protocol_under_address_and_ub_sanitizers():
+    """The same scenarios (4 ranks for the long comparison, every failure path) built with -fsanitize=address,undefined: no
+    use-after-free on the stop / abort / abandon / destroy paths, no undefined behaviour.  (Leak detection off: an abandoned
+    handle and the simulated communicators are leaked on purpose.)"""
+    cxx = _tsan_compiler()
+    out = "_build_asan"
+    subprocess.check_call(["make", "-C", SIM, "CXX=" + cxx, "SAN=-fsanitize=address,undefined -fno-omit-frame-pointer", "OUT=" + out],
+                          stdout=subprocess.DEVNULL)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    p = subprocess.run([os.path.join(SIM, out, "multi_sim"), "quick"], capture_output=True, text=True, timeout=900, env=env)
+    report = p.stdout + "\n" + p.stderr[-6000:]
+    assert p.returncode == 0 and "AddressSanitizer" not in p.stderr and "runtime error" not in p.stderr, report
+    assert not [ln for ln in p.stdout.splitlines() if ln.startswith("NOT ok")], report
