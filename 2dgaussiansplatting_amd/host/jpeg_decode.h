@@ -350,37 +350,39 @@ struct JpegDecoder {
     }
 
     // ---- inverse DCT: the IJG "islow" algorithm (jidctint.c), 13-bit constants, two passes ----
+    // (64-bit intermediates: on a valid stream no product leaves 32 bits and the results are jidctint.c's to the bit; on a corrupt
+    // one -- coefficients up to 2^15 times quantiser steps up to 2^16 -- nothing overflows a signed integer either)
     static void idct_islow(const int16_t* in, const uint16_t* q, uint8_t* out, int stride)
     {
         const int CB = 13, P1 = 2;
-        const int32_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299,
+        const int64_t F0_298 = 2446, F0_390 = 3196, F0_541 = 4433, F0_765 = 6270, F0_899 = 7373, F1_175 = 9633, F1_501 = 12299,
                       F1_847 = 15137, F1_961 = 16069, F2_053 = 16819, F2_562 = 20995, F3_072 = 25172;
-        int32_t ws[64];
+        int64_t ws[64];
         for (int c = 0; c < 8; c++) { // pass 1: columns
             const int16_t* ip = in + c;
             const uint16_t* qp = q + c;
-            int32_t* wp = ws + c;
+            int64_t* wp = ws + c;
             if (!ip[8] && !ip[16] && !ip[24] && !ip[32] && !ip[40] && !ip[48] && !ip[56]) {
-                const int32_t dcv = (int32_t)(ip[0] * qp[0]) * (1 << P1);
+                const int64_t dcv = ((int64_t)ip[0] * qp[0]) * (1 << P1);
                 for (int r = 0; r < 8; r++) wp[8 * r] = dcv;
                 continue;
             }
-            int32_t z2 = ip[16] * qp[16], z3 = ip[48] * qp[48];
-            int32_t z1 = (z2 + z3) * F0_541;
-            int32_t tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
-            z2 = ip[0] * qp[0];
-            z3 = ip[32] * qp[32];
-            int32_t tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
-            const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
-            tmp0 = ip[56] * qp[56];
-            tmp1 = ip[40] * qp[40];
-            tmp2 = ip[24] * qp[24];
-            tmp3 = ip[8] * qp[8];
+            int64_t z2 = (int64_t)ip[16] * qp[16], z3 = (int64_t)ip[48] * qp[48];
+            int64_t z1 = (z2 + z3) * F0_541;
+            int64_t tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
+            z2 = (int64_t)ip[0] * qp[0];
+            z3 = (int64_t)ip[32] * qp[32];
+            int64_t tmp0 = (z2 + z3) * (1 << CB), tmp1 = (z2 - z3) * (1 << CB);
+            const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+            tmp0 = (int64_t)ip[56] * qp[56];
+            tmp1 = (int64_t)ip[40] * qp[40];
+            tmp2 = (int64_t)ip[24] * qp[24];
+            tmp3 = (int64_t)ip[8] * qp[8];
             z1 = tmp0 + tmp3;
             z2 = tmp1 + tmp2;
             z3 = tmp0 + tmp2;
-            int32_t z4 = tmp1 + tmp3;
-            const int32_t z5 = (z3 + z4) * F1_175;
+            int64_t z4 = tmp1 + tmp3;
+            const int64_t z5 = (z3 + z4) * F1_175;
             tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
             z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
             z3 += z5; z4 += z5;
@@ -392,24 +394,24 @@ struct JpegDecoder {
             wp[24] = (tmp13 + tmp0 + rnd) >> sh; wp[32] = (tmp13 - tmp0 + rnd) >> sh;
         }
         for (int r = 0; r < 8; r++) { // pass 2: rows
-            const int32_t* wp = ws + 8 * r;
+            const int64_t* wp = ws + 8 * r;
             uint8_t* op = out + (size_t)r * stride;
             const int sh = CB + P1 + 3, rnd = 1 << (sh - 1);
-            auto clamp = [](int32_t v) { v += 128; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
+            auto clamp = [](int64_t v) { v += 128; return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); };
             if (!wp[1] && !wp[2] && !wp[3] && !wp[4] && !wp[5] && !wp[6] && !wp[7]) {
                 const uint8_t dcv = clamp((wp[0] + (1 << (P1 + 2))) >> (P1 + 3));
                 for (int c = 0; c < 8; c++) op[c] = dcv;
                 continue;
             }
-            int32_t z2 = wp[2], z3 = wp[6];
-            int32_t z1 = (z2 + z3) * F0_541;
-            int32_t tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
-            int32_t tmp0 = (wp[0] + wp[4]) * (1 << CB), tmp1 = (wp[0] - wp[4]) * (1 << CB);
-            const int32_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+            int64_t z2 = wp[2], z3 = wp[6];
+            int64_t z1 = (z2 + z3) * F0_541;
+            int64_t tmp2 = z1 + z3 * (-F1_847), tmp3 = z1 + z2 * F0_765;
+            int64_t tmp0 = (wp[0] + wp[4]) * (1 << CB), tmp1 = (wp[0] - wp[4]) * (1 << CB);
+            const int64_t tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
             tmp0 = wp[7]; tmp1 = wp[5]; tmp2 = wp[3]; tmp3 = wp[1];
             z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-            int32_t z4 = tmp1 + tmp3;
-            const int32_t z5 = (z3 + z4) * F1_175;
+            int64_t z4 = tmp1 + tmp3;
+            const int64_t z5 = (z3 + z4) * F1_175;
             tmp0 *= F0_298; tmp1 *= F2_053; tmp2 *= F3_072; tmp3 *= F1_501;
             z1 *= -F0_899; z2 *= -F2_562; z3 *= -F1_961; z4 *= -F0_390;
             z3 += z5; z4 += z5;
