@@ -275,6 +275,41 @@ def test_training_steps_random_sweep(seed):
     assert np.abs(sp - ws).max() <= 5 * 1e-3 * 0.05 + 1e-5 * np.abs(ws).max(), np.abs(sp - ws).max()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_garbage_parameters_neither_fault_nor_hang(seed):
+    """s2d_set_splats is handed whatever the caller has: huge, tiny, zero and negative scales, positions far off the image,
+    infinities and NaNs.  Outside the reference's contract (its finite guard abort()s such a state after the next Adam step,
+    main.cpp:752-785) -- but the kernels must stay inside their buffers and return: forward, backward and a step complete, the
+    step reports S2D_E_NONFINITE or succeeds, and the library works normally afterwards."""
+    rng = np.random.default_rng(900 + seed)
+    W, H, n = 300, 200, 1500
+    s = random_splats(n, W, H, 50 + seed)
+    bad = rng.choice(n, 300, replace=False)
+    pool = np.array([0.0, -1.0, -1e30, 1e30, 1e-30, np.inf, -np.inf, np.nan, 3.4e38, 1e-45, 65536.0, -0.0], dtype=np.float32)
+    raw = s.view(np.float32).reshape(n, 9)
+    for i in bad:
+        for k in rng.choice(9, int(rng.integers(1, 5)), replace=False):
+            raw[i, k] = rng.choice(pool)
+    tgt = O.synthetic_target(W, H)
+    with S2D.Trainer(W, H, n) as t:
+        t.set_target(tgt)
+        t.set_splats(s)
+        t.forward()
+        img = t.get_image()
+        t.backward()
+        g = t.get_grads()
+        assert img.shape == (H, W, 4) and g.shape == (n,)
+        try:
+            t.step(2)
+        except S2D.S2DError as e:
+            assert e.code == 3, e           # S2D_E_NONFINITE: where the reference would abort()
+    # the library is still in working order afterwards
+    with S2D.Trainer(64, 64, 50) as t:
+        t.set_target_synthetic()
+        t.init()
+        assert np.isfinite(t.step(3)).all()
+
+
 def test_forward_no_splats():
     with S2D.Trainer(40, 30, 0) as t:
         t.set_target(O.synthetic_target(40, 30))
