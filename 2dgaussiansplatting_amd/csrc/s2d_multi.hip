@@ -378,9 +378,7 @@ inline bool stopped(s2d_multi* m, int rank)
     return true;
 }
 
-// Barrier of the rank threads; false once some rank has failed (the caller stops) or did not arrive in time.
-
-// meet() for a rank: S2D_OK, kStopped (somebody else failed), or S2D_E_STATE when the wait itself ran out -- some rank
+// The rendezvous of the rank threads, for a rank: S2D_OK, kStopped (somebody else failed), or S2D_E_STATE when the wait itself ran out -- some rank
 // never arrived; the first rank to notice reports it.
 int meet_rank(s2d_multi* m, int r, const char* where)
 {
@@ -405,7 +403,7 @@ int meet_rank(s2d_multi* m, int r, const char* where)
     return kStopped;
 }
 
-// Wait, with a bound, until everything queued on rank r's stream so far has run.  hipStreamSynchronize would wait for
+// Wait, with a bound, until event `ev` (recorded on rank r's stream) has completed.  hipStreamSynchronize would wait for
 // ever behind a kernel that never ends (a collective whose peer is gone, a device that stopped); an event and a poll
 // let the thread notice a stop published by another rank, abort its own collective, and give up with a report.
 int wait_event(s2d_multi* m, int r, hipEvent_t ev, const char* what)
